@@ -1,0 +1,211 @@
+/*
+ * ofx.h -- C ABI of the MI355X-native optical-flow hot path (libofx.so).
+ *
+ * Drop-in boundary for the flow / warp / mask path of zyddnys/sd_animation_optical_flow.
+ * Every entry point takes plain device pointers and sizes plus a `hipStream_t` passed as void*;
+ * there are no torch types in any signature.  All functions return 0 on success, a positive
+ * hipError_t on a HIP failure, or a negative OFX_E* code on a precondition failure (the reference's
+ * TORCH_CHECKs, RAFT/alt_cuda_corr/correlation.cpp:19-21, become return codes).  Work is enqueued
+ * on the given stream and is asynchronous, like the reference's launches.
+ *
+ * Reference interface each group replaces (file:line relative to the reference repo):
+ *   ofx_local_corr_fwd          RAFT/alt_cuda_corr/correlation.cpp:23-33,51-54  (alt_cuda_corr.forward)
+ *                               RAFT/alt_cuda_corr/correlation_kernel.cu:18-119,260-286
+ *   ofx_corr_volume / _lookup   RAFT/core/corr.py:13-60   (CorrBlock)
+ *   ofx_conv2d, ofx_inorm_*     RAFT/core/extractor.py:118-192, RAFT/core/update.py:6-136
+ *   ofx_upsample_flow           RAFT/core/raft.py:72-83
+ *   ofx_raft_*                  RAFT/core/raft.py:86-144 ; ofgen_keyframe_inpaint.py:47-71 (RAFT_2)
+ *   ofx_warp_*                  pdcnet_of.py:34-42 ; ofgen_keyframe_inpaint.py:92-98 (cv2.remap)
+ *   ofx_generate_mask, ofx_dilate_u8, ofx_expand_mask, ofx_travel_distance, ofx_merge_images,
+ *   ofx_mix_frames, ofx_conf_sum, ofx_compose_step
+ *                               ofgen_keyframe_inpaint.py:113-133,237-248,306-322,676-688,968-973,995-1027
+ *
+ * Layout conventions: images and flow are HWC ("channels-last"); network activations are
+ * NHWC fp32; a flow field is f32[H,W,2] = (dx, dy) exactly as `algo.calc` returns it
+ * (pdcnet_of.py:72).
+ */
+#ifndef OFX_H
+#define OFX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define OFX_VERSION 100
+
+/* negative error codes (positive values are hipError_t) */
+#define OFX_EINVAL   (-1)   /* bad argument (null pointer, non-positive size, unsupported mode) */
+#define OFX_EALIGN   (-2)   /* pointer / leading dimension not 16-byte aligned where required   */
+#define OFX_ENOMEM   (-3)   /* workspace too small                                             */
+#define OFX_EKEY     (-4)   /* weight tensor missing or of the wrong shape                      */
+#define OFX_ENODEV   (-5)   /* no gfx950 device                                                 */
+
+int ofx_version(void);
+const char* ofx_error_string(int code);
+
+/* ---------------------------------------------------------------- profiling (HIP events) */
+/* When enabled, every kernel launch issued through this library is bracketed by a pair of
+ * hipEvents recorded on the launch stream.  ofx_prof_collect synchronises, accumulates the elapsed
+ * times per kernel name and writes a JSON object {"name": {"calls": n, "ms": total}, ...}. */
+int ofx_prof_enable(int on);
+int ofx_prof_collect(char* json_out, size_t cap);
+
+/* ---------------------------------------------------------------- warp */
+#define OFX_WARP_BILINEAR  0   /* grid_sample(bilinear, zeros, align_corners=True) semantics  */
+#define OFX_WARP_BICUBIC   1   /* float Keys cubic A=-0.75, zero border                        */
+#define OFX_WARP_CV2_CUBIC 2   /* OpenCV remap INTER_CUBIC: 1/32-px coords, 15-bit weights     */
+
+/* out[b,y,x,:] = frame[b', y + sign*flow[b,y,x,1], x + sign*flow[b,y,x,0], :].
+ * frame_bstride = elements between consecutive frames (0 = one shared key frame for all B flows).
+ * sign = +1: pdcnet_of.warp_frame; sign = -1: the RAFT-convention warp_frame. C in [1,4]. */
+int ofx_warp_u8(const uint8_t* frame, long frame_bstride, const float* flow, uint8_t* out,
+                int B, int H, int W, int C, int mode, float sign, void* stream);
+int ofx_warp_f32(const float* frame, long frame_bstride, const float* flow, float* out,
+                 int B, int H, int W, int C, int mode, float sign, void* stream);
+/* cv2.resize(INTER_CUBIC) of an f32 HWC image (used by warp_frame_latent, pdcnet_of.py:24,30) */
+int ofx_resize_cubic_f32(const float* src, float* dst, int B, int Hs, int Ws, int Hd, int Wd, int C,
+                         void* stream);
+
+/* ---------------------------------------------------------------- masks */
+/* mask = dilate(255*(conf < thres), ellipse ksize); if log_conf != NULL, log_conf[conf<thres] = 0
+ * in place (generate_mask, ofgen_keyframe_inpaint.py:317-322).  cmp_gt = 0: low = conf < thres;
+ * cmp_gt = 1: low = !(conf > thres) (the keyframe path's convention, :995). ksize odd, <= 31;
+ * ksize = 1 means no dilation. */
+int ofx_generate_mask(const float* conf, float* log_conf, uint8_t* mask, int B, int H, int W,
+                      float thres, int ksize, int cmp_gt, void* stream);
+int ofx_dilate_u8(const uint8_t* in, uint8_t* out, int B, int H, int W, int ksize, void* stream);
+/* out = mask | dilate(255*(gray(|laplacian(image)| mod 256) > edge_thres), ellipse ksize) */
+int ofx_expand_mask(const uint8_t* mask, const uint8_t* image_bgr, uint8_t* out, uint8_t* scratch,
+                    int B, int H, int W, int edge_thres, int ksize, void* stream);
+/* v = |flow| with v[conf < conf_floor] = 0 (of_calc, ofgen_keyframe_inpaint.py:118-126) */
+int ofx_travel_distance(const float* flow, const float* conf, float* out, int B, int H, int W,
+                        float conf_floor, void* stream);
+/* confidence_to_mask (:237-248): travel' = warp(travel, flow) + dist; travel'[conf<0.9] = 0;
+ * raw = 255*(conf<0.9 | travel' > thres); travel'[travel'>thres] = 0.  `raw` is un-dilated; the
+ * caller dilates with ofx_dilate_u8(ksize=15). travel_in and travel_out must not alias. */
+int ofx_travel_mask(const float* conf, const float* flow, const float* dist, const float* travel_in,
+                    float* travel_out, uint8_t* raw, int B, int H, int W, float thres, int warp_mode,
+                    void* stream);
+/* merge_images 'naive' (:676-681): out = base*(1-m) + second*m with m = (mask==255) */
+int ofx_merge_images(const uint8_t* base, const uint8_t* second, const uint8_t* mask, uint8_t* out,
+                     int B, int H, int W, int C, void* stream);
+/* mix_propagated_ai_frame (:306-315) */
+int ofx_mix_frames(const uint8_t* raw, const uint8_t* warped, const uint8_t* mask, uint8_t* out,
+                   int B, int H, int W, int C, float ppw, void* stream);
+/* sums[n] = sum over HW of conf_like[n, :, :, chan] for a f32[N,H,W,nchan] tensor (f64 accumulate);
+ * used for `einops.reduce(flow_mat[...,2], 's t h w -> s', 'sum')` (:666, :1000) */
+int ofx_conf_sum(const float* x, double* sums, int N, long HW, int nchan, int chan, void* stream);
+/* EXTENSION (no reference counterpart: RAFT emits no confidence and PDCNet+ is not in the reference
+ * tree): forward-backward consistency confidence.  flow_fw f32[B,H,W,2] is defined on the target
+ * grid, flow_bw on the source grid; e = fw(p) + bw(p + fw(p)); log_conf = -|e|^2/(2 sigma^2);
+ * conf = exp(log_conf), shaped like PDCNetPlus.calc's (confidence, log_confidence), pdcnet_of.py:73-74 */
+int ofx_fb_confidence(const float* flow_fw, const float* flow_bw, float* conf, float* log_conf, int B,
+                      int H, int W, float sigma, void* stream);
+/* fused hot-path tail: warped = warp(frame, flow); mask = dilate(255*(conf<thres)) in one call. */
+int ofx_warp_and_mask(const uint8_t* frame, long frame_bstride, const float* flow, const float* conf,
+                      uint8_t* warped, uint8_t* mask, int B, int H, int W, int C, int warp_mode,
+                      float sign, float thres, int ksize, int cmp_gt, void* stream);
+
+/* ---------------------------------------------------------------- implicit-GEMM conv */
+#define OFX_ACT_NONE    0
+#define OFX_ACT_RELU    1
+#define OFX_ACT_SIGMOID 2
+#define OFX_ACT_TANH    3
+
+#define OFX_EPI_PLAIN   0   /* y = act(acc*scale + shift); if res: y = relu(y + res)            */
+#define OFX_EPI_GRU_ZR  1   /* Cout=2*hd: n<hd -> z=sigmoid -> aux_z ; n>=hd -> r -> aux_rh=r*h   */
+#define OFX_EPI_GRU_Q   2   /* q=tanh; h = (1-z)*h + z*q written in place to aux_h               */
+#define OFX_EPI_FLOW    3   /* Cout=2: coords1 += delta; flow=coords1-grid -> aux_h slot + flow4 */
+
+typedef struct ofx_conv_desc {
+    /* input: NHWC fp32, up to two channel segments (torch.cat along C without materialising) */
+    const float* in0; int ld0; int c0;
+    const float* in1; int ld1; int c1;          /* in1 may be NULL (c1 = 0) */
+    /* weights packed [Cout][Kpad], k = (ky*KW + kx)*(c0+c1) + c, Kpad = K rounded up to 32 */
+    const float* w;
+    const float* scale;                          /* [Cout] or NULL (=1) */
+    const float* shift;                          /* [Cout] or NULL (=0) */
+    float* out; int ldo;                         /* out[m*ldo + n]; may be NULL for GRU/FLOW epilogues */
+    const float* res; int ldres;                 /* residual for EPI_PLAIN, or NULL */
+    const float* nmean; const float* nrstd;      /* instance-norm(+ReLU) applied to in0 on load, [B][c0], or NULL */
+    float* aux_z; float* aux_rh; float* aux_h; int ldh;   /* GRU buffers; hidden dim = Cout(Q) */
+    float* aux_coords; float* aux_flow4;         /* EPI_FLOW state: coords1 [M][2], flow4 [M][4] */
+    long a_zs, w_zs, o_zs; int nz;               /* batched-GEMM mode (nz>1): per-z strides in elements */
+    int B, Hin, Win, Hout, Wout, Cout, KH, KW, stride, padH, padW;
+    int act, epi;
+    int tile;                                    /* 0 = auto; else BM*1000+BN, e.g. 128128 */
+} ofx_conv_desc;
+
+int ofx_conv2d(const ofx_conv_desc* d, void* stream);
+/* host-side helper: OIHW fp32 -> packed [Cout][Kpad] with Cin padded to cin_pad (>= Cin, %4==0).
+ * Returns Kpad (or negative error).  `out` may be NULL to query the size. */
+long ofx_pack_conv_weight(const float* w_oihw, int Cout, int Cin, int KH, int KW, int cin_pad,
+                          float* out);
+
+/* instance norm statistics over HW per (b,c): mean and 1/sqrt(var+eps) (biased var), NHWC input */
+int ofx_inorm_stats(const float* x, int ld, float* mean, float* rstd, float* scratch,
+                    int B, long HW, int C, float eps, void* stream);
+/* out = relu?( (x-mean)*rstd ) ; with res: out = relu( r + relu((x-mean)*rstd) ) where
+ * r = res (res_mean==NULL) or (res-res_mean)*res_rstd */
+int ofx_inorm_apply(const float* x, const float* mean, const float* rstd, const float* res,
+                    const float* res_mean, const float* res_rstd, float* out, int B, long HW, int C,
+                    int relu, void* stream);
+/* u8 HWC3 image -> f32 NHWC4 (4th channel 0), value 2*(x/255)-1 (raft.py:89-90); bgr=1 swaps to RGB */
+int ofx_preprocess_u8(const uint8_t* img, float* out, long npix, int bgr, void* stream);
+
+/* ---------------------------------------------------------------- correlation */
+/* vol0[b,i,j] = <f1[b,i,:], f2[b,j,:]> / sqrt(D) and the avg-pooled pyramid (CorrBlock.__init__).
+ * f1,f2: [B, h*w, D] (NHWC); pyr[l]: [B*h*w, h_l*w_l], h_l = h >> l (floor). levels in [1,4]. */
+int ofx_corr_volume(const float* f1, const float* f2, float* const* pyr, int B, int h, int w, int D,
+                    int levels, void* stream);
+/* CorrBlock.__call__: out[m, l*(2r+1)^2 + i*(2r+1) + j] for coords [B*h*w][2]; out row stride ldo */
+int ofx_corr_lookup(const float* const* pyr, const float* coords, float* out, int ldo, int B, int h,
+                    int w, int levels, int radius, void* stream);
+/* alt_cuda_corr.forward: fmap1 [B,H1,W1,C], fmap2 [B,H2,W2,C], coords [B,N,H1,W1,2] ->
+ * corr [B,N,(2r+1)^2,H1,W1] (overwritten, not accumulated into).  C % 4 == 0. */
+int ofx_local_corr_fwd(const float* fmap1, const float* fmap2, const float* coords, float* corr,
+                       int B, int H1, int W1, int H2, int W2, int C, int N, int r, void* stream);
+/* 2x2 average pool of an NHWC tensor (AlternateCorrBlock pyramid, corr.py:68-72) */
+int ofx_avgpool2_nhwc(const float* in, float* out, int B, int H, int W, int C, void* stream);
+
+/* convex 8x upsample: coords1 [B*h*w][2], mask [B*h*w][576] -> flow_up f32[B, 8h, 8w, 2] */
+int ofx_upsample_flow(const float* coords1, const float* mask, float* flow_up, int B, int h, int w,
+                      void* stream);
+
+/* ---------------------------------------------------------------- RAFT engine */
+typedef struct ofx_tensor {            /* one entry of a checkpoint state_dict (host memory, fp32) */
+    const char* name;                  /* reference key, e.g. "fnet.layer1.0.conv1.weight"        */
+    const float* data;
+    int ndim; long shape[4];
+} ofx_tensor;
+
+typedef struct ofx_raft ofx_raft;      /* opaque */
+
+/* Builds the engine on the current device: packs and uploads all weights (folds cnet BatchNorm into
+ * per-channel scale/shift).  Keys may carry the "module." DataParallel prefix. */
+int ofx_raft_create(const ofx_tensor* tensors, int n, ofx_raft** out);
+int ofx_raft_destroy(ofx_raft* r);
+/* bytes of device workspace needed for a batch of B pairs of HxW images (H,W multiples of 8) */
+size_t ofx_raft_workspace_bytes(const ofx_raft* r, int B, int H, int W);
+
+#define OFX_RAFT_BGR          1   /* input images are BGR (calc) instead of RGB (calc_batch)       */
+#define OFX_RAFT_SHARED_IMG2  2   /* image2 is ONE image shared by the whole batch (key frame)     */
+#define OFX_RAFT_SHARED_IMG1  4   /* image1 is ONE image shared by the whole batch                 */
+#define OFX_RAFT_ALT_CORR     8   /* on-the-fly local correlation instead of the volume (alt_cuda_corr) */
+
+/* RAFT.forward(test_mode=True): image1/image2 u8 [B,H,W,3] on device -> flow_up f32[B,H,W,2]
+ * (flow on image1's grid pointing into image2) and, if non-NULL, flow_low f32[B,H/8,W/8,2]. */
+int ofx_raft_forward(ofx_raft* r, const uint8_t* image1, const uint8_t* image2, int B, int H, int W,
+                     int iters, int flags, float* flow_up, float* flow_low, void* workspace,
+                     size_t workspace_bytes, void* stream);
+/* debug / stage-parity access to the buffers of the last forward: returns a device pointer and
+ * element count for a named intermediate ("fmap1","fmap2","hx","corr","pyr0".."pyr3","mask",...) */
+int ofx_raft_buffer(const ofx_raft* r, const char* name, void** ptr, size_t* nfloats);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OFX_H */

@@ -1,0 +1,256 @@
+// Streaming kernels around the convolutions of the flow network: image pre-processing, instance
+// normalisation (statistics + apply), and the convex 8x flow upsample.  All are HBM-bound, read and
+// write every byte once, and use 16-byte per-lane accesses on NHWC rows.
+//
+//   preprocess      RAFT/core/raft.py:89-90   (2*(x/255)-1), plus BGR->RGB of RAFT_2.calc
+//   instance norm   RAFT/core/extractor.py:27-31,123-124 (nn.InstanceNorm2d: no affine, eps=1e-5, biased var)
+//   residual merge  RAFT/core/extractor.py:46-56
+//   convex upsample RAFT/core/raft.py:72-83
+#include "ofx_internal.h"
+
+namespace {
+
+__global__ __launch_bounds__(256) void preprocess_kernel(const uint8_t* __restrict__ img, float* __restrict__ out,
+                                                         long npix, int bgr) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < npix; i += (long)gridDim.x * blockDim.x) {
+        const uint8_t* p = img + i * 3;
+        const float c0 = (float)p[bgr ? 2 : 0], c1 = (float)p[1], c2 = (float)p[bgr ? 0 : 2];
+        float4 o;
+        o.x = __fsub_rn(__fmul_rn(2.0f, __fdiv_rn(c0, 255.0f)), 1.0f);
+        o.y = __fsub_rn(__fmul_rn(2.0f, __fdiv_rn(c1, 255.0f)), 1.0f);
+        o.z = __fsub_rn(__fmul_rn(2.0f, __fdiv_rn(c2, 255.0f)), 1.0f);
+        o.w = 0.f;
+        reinterpret_cast<float4*>(out)[i] = o;
+    }
+}
+
+// ---- instance-norm statistics: per (b, slice) partial sums in f64, then a finalize pass
+constexpr int kSlices = 64;
+
+__global__ __launch_bounds__(256) void inorm_partial_kernel(const float* __restrict__ x, int ld, double* __restrict__ part,
+                                                            long HW, int C) {
+    // grid: (kSlices, B).  Threads: (C/4) channel groups x rows.
+    const int cg = C / 4;
+    const int rows = 256 / cg;
+    const int tc = threadIdx.x % cg, tr = threadIdx.x / cg;
+    const int b = blockIdx.y, sl = blockIdx.x;
+    const long per = (HW + kSlices - 1) / kSlices;
+    const long beg = sl * per, end = beg + per < HW ? beg + per : HW;
+    double s[4] = {0, 0, 0, 0}, q[4] = {0, 0, 0, 0};
+    if (tr < rows) {
+        const float* base = x + ((long)b * HW) * ld + tc * 4;
+        for (long i = beg + tr; i < end; i += rows) {
+            const float4 v = *reinterpret_cast<const float4*>(base + i * ld);
+            s[0] += v.x; s[1] += v.y; s[2] += v.z; s[3] += v.w;
+            q[0] += (double)v.x * v.x; q[1] += (double)v.y * v.y; q[2] += (double)v.z * v.z; q[3] += (double)v.w * v.w;
+        }
+    }
+    __shared__ double red[256 * 8];
+    for (int k = 0; k < 4; ++k) {
+        red[threadIdx.x * 8 + k] = s[k];
+        red[threadIdx.x * 8 + 4 + k] = q[k];
+    }
+    __syncthreads();
+    if (threadIdx.x < cg) {
+        double ts[4] = {0, 0, 0, 0}, tq[4] = {0, 0, 0, 0};
+        for (int r = 0; r < rows; ++r)
+            for (int k = 0; k < 4; ++k) {
+                ts[k] += red[(r * cg + threadIdx.x) * 8 + k];
+                tq[k] += red[(r * cg + threadIdx.x) * 8 + 4 + k];
+            }
+        double* o = part + (((long)b * kSlices + sl) * C + threadIdx.x * 4) * 2;
+        for (int k = 0; k < 4; ++k) {
+            o[k * 2] = ts[k];
+            o[k * 2 + 1] = tq[k];
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void inorm_finalize_kernel(const double* __restrict__ part, float* __restrict__ mean,
+                                                             float* __restrict__ rstd, long HW, int C, int total, float eps) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;   // over B*C
+    if (i >= total) return;
+    const int b = i / C, c = i - b * C;
+    double s = 0, q = 0;
+    for (int sl = 0; sl < kSlices; ++sl) {
+        const double* o = part + (((long)b * kSlices + sl) * C + c) * 2;
+        s += o[0];
+        q += o[1];
+    }
+    const double mu = s / (double)HW;
+    double var = q / (double)HW - mu * mu;
+    if (var < 0) var = 0;
+    mean[i] = (float)mu;
+    rstd[i] = (float)(1.0 / sqrt(var + (double)eps));
+}
+
+__global__ __launch_bounds__(256) void inorm_apply_kernel(const float* __restrict__ x, const float* __restrict__ mean,
+                                                          const float* __restrict__ rstd, const float* __restrict__ res,
+                                                          const float* __restrict__ rmean, const float* __restrict__ rrstd,
+                                                          float* __restrict__ out, long HW, int C, long total4, int relu) {
+    const int cg = C / 4;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % cg) * 4;
+        const long pix = i / cg;
+        const long b = pix / HW;
+        const float4 v = reinterpret_cast<const float4*>(x)[i];
+        const float4 mu = *reinterpret_cast<const float4*>(mean + b * C + c);
+        const float4 rs = *reinterpret_cast<const float4*>(rstd + b * C + c);
+        float4 y;
+        y.x = (v.x - mu.x) * rs.x; y.y = (v.y - mu.y) * rs.y; y.z = (v.z - mu.z) * rs.z; y.w = (v.w - mu.w) * rs.w;
+        if (relu || res) {
+            y.x = fmaxf(y.x, 0.f); y.y = fmaxf(y.y, 0.f); y.z = fmaxf(y.z, 0.f); y.w = fmaxf(y.w, 0.f);
+        }
+        if (res) {
+            float4 r = reinterpret_cast<const float4*>(res)[i];
+            if (rmean) {
+                const float4 m2 = *reinterpret_cast<const float4*>(rmean + b * C + c);
+                const float4 s2 = *reinterpret_cast<const float4*>(rrstd + b * C + c);
+                r.x = (r.x - m2.x) * s2.x; r.y = (r.y - m2.y) * s2.y; r.z = (r.z - m2.z) * s2.z; r.w = (r.w - m2.w) * s2.w;
+            }
+            y.x = fmaxf(r.x + y.x, 0.f); y.y = fmaxf(r.y + y.y, 0.f); y.z = fmaxf(r.z + y.z, 0.f); y.w = fmaxf(r.w + y.w, 0.f);
+        }
+        reinterpret_cast<float4*>(out)[i] = y;
+    }
+}
+
+// ---- convex upsample: one wavefront per coarse pixel, lane = (i*8 + j) sub-pixel
+__global__ __launch_bounds__(256) void upsample_kernel(const float* __restrict__ coords1, const float* __restrict__ mask,
+                                                       float* __restrict__ flow_up, int h, int w, long M) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long m = (long)blockIdx.x * 4 + wave;
+    if (m >= M) return;
+    const long hw = (long)h * w;
+    const long b = m / hw;
+    const int rem = (int)(m - b * hw);
+    const int y = rem / w, x = rem - y * w;
+    const float* mk = mask + m * 576;
+    float lg[9];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+        lg[k] = mk[k * 64 + lane];
+        mx = fmaxf(mx, lg[k]);
+    }
+    float den = 0.f;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+        lg[k] = expf(lg[k] - mx);
+        den += lg[k];
+    }
+    float ax = 0.f, ay = 0.f;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+        const int yy = y + k / 3 - 1, xx = x + k % 3 - 1;
+        float fx = 0.f, fy = 0.f;
+        if ((unsigned)yy < (unsigned)h && (unsigned)xx < (unsigned)w) {
+            const float2 c = reinterpret_cast<const float2*>(coords1)[b * hw + (long)yy * w + xx];
+            fx = 8.0f * (c.x - (float)xx);    // 8 * (coords1 - coords0)
+            fy = 8.0f * (c.y - (float)yy);
+        }
+        const float wgt = lg[k] / den;
+        ax += wgt * fx;
+        ay += wgt * fy;
+    }
+    const int i = lane >> 3, j = lane & 7;
+    const long W8 = (long)w * 8;
+    float2* o = reinterpret_cast<float2*>(flow_up) + (b * h * 8 + (long)y * 8 + i) * W8 + (long)x * 8 + j;
+    *o = make_float2(ax, ay);
+}
+
+// coords1 = pixel grid, flow4 = 0, hx[:, flow_off:flow_off+2] = 0   (RAFT.initialize_flow, raft.py:63-70)
+__global__ __launch_bounds__(256) void init_state_kernel(float* __restrict__ coords1, float* __restrict__ flow4,
+                                                         float* __restrict__ hx, int ldh, int flow_off, int h, int w, long M) {
+    for (long m = (long)blockIdx.x * blockDim.x + threadIdx.x; m < M; m += (long)gridDim.x * blockDim.x) {
+        const int rem = (int)(m % ((long)h * w));
+        const int y = rem / w, x = rem - y * w;
+        reinterpret_cast<float2*>(coords1)[m] = make_float2((float)x, (float)y);
+        reinterpret_cast<float4*>(flow4)[m] = make_float4(0.f, 0.f, 0.f, 0.f);
+        hx[m * ldh + flow_off] = 0.f;
+        hx[m * ldh + flow_off + 1] = 0.f;
+    }
+}
+
+__global__ __launch_bounds__(256) void coords_to_flow_kernel(const float* __restrict__ coords1, float* __restrict__ flow,
+                                                             int h, int w, long M) {
+    for (long m = (long)blockIdx.x * blockDim.x + threadIdx.x; m < M; m += (long)gridDim.x * blockDim.x) {
+        const int rem = (int)(m % ((long)h * w));
+        const int y = rem / w, x = rem - y * w;
+        const float2 c = reinterpret_cast<const float2*>(coords1)[m];
+        reinterpret_cast<float2*>(flow)[m] = make_float2(c.x - (float)x, c.y - (float)y);
+    }
+}
+
+}  // namespace
+
+int ofx_init_state(float* coords1, float* flow4, float* hx, int ldh, int flow_off, int B, int h, int w, hipStream_t s) {
+    const long M = (long)B * h * w;
+    OfxProfScope prof("init_state", s);
+    hipLaunchKernelGGL(init_state_kernel, dim3((unsigned)std::min<long>((M + 255) / 256, 8192)), dim3(256), 0, s, coords1,
+                       flow4, hx, ldh, flow_off, h, w, M);
+    return ofx_launch_status();
+}
+
+int ofx_coords_to_flow(const float* coords1, float* flow, int B, int h, int w, hipStream_t s) {
+    const long M = (long)B * h * w;
+    OfxProfScope prof("coords_to_flow", s);
+    hipLaunchKernelGGL(coords_to_flow_kernel, dim3((unsigned)std::min<long>((M + 255) / 256, 8192)), dim3(256), 0, s,
+                       coords1, flow, h, w, M);
+    return ofx_launch_status();
+}
+
+extern "C" {
+
+int ofx_preprocess_u8(const uint8_t* img, float* out, long npix, int bgr, void* stream) {
+    OFX_REQUIRE(img && out && npix > 0, OFX_EINVAL);
+    OFX_REQUIRE(ofx_aligned16(out), OFX_EALIGN);
+    hipStream_t s = (hipStream_t)stream;
+    OfxProfScope prof("preprocess_u8", s);
+    hipLaunchKernelGGL(preprocess_kernel, dim3((unsigned)std::min<long>((npix + 255) / 256, 16384)), dim3(256), 0, s, img,
+                       out, npix, bgr);
+    return ofx_launch_status();
+}
+
+int ofx_inorm_stats(const float* x, int ld, float* mean, float* rstd, float* scratch, int B, long HW, int C, float eps,
+                    void* stream) {
+    OFX_REQUIRE(x && mean && rstd && scratch && B > 0 && HW > 0 && C > 0, OFX_EINVAL);
+    OFX_REQUIRE(C % 4 == 0 && C / 4 <= 256 && ld % 4 == 0 && ld >= C && ofx_aligned16(x), OFX_EALIGN);
+    OFX_REQUIRE((((uintptr_t)scratch) & 7u) == 0, OFX_EALIGN);
+    hipStream_t s = (hipStream_t)stream;
+    double* part = reinterpret_cast<double*>(scratch);   // needs B*kSlices*C*2 doubles
+    {
+        OfxProfScope prof("inorm_stats", s);
+        hipLaunchKernelGGL(inorm_partial_kernel, dim3(kSlices, B), dim3(256), 0, s, x, ld, part, HW, C);
+    }
+    int st = ofx_launch_status();
+    if (st) return st;
+    const int total = B * C;
+    OfxProfScope prof("inorm_finalize", s);
+    hipLaunchKernelGGL(inorm_finalize_kernel, dim3(ofx_cdiv(total, 256)), dim3(256), 0, s, part, mean, rstd, HW, C, total, eps);
+    return ofx_launch_status();
+}
+
+int ofx_inorm_apply(const float* x, const float* mean, const float* rstd, const float* res, const float* res_mean,
+                    const float* res_rstd, float* out, int B, long HW, int C, int relu, void* stream) {
+    OFX_REQUIRE(x && mean && rstd && out && B > 0 && HW > 0 && C > 0, OFX_EINVAL);
+    OFX_REQUIRE(C % 4 == 0 && ofx_aligned16(x) && ofx_aligned16(out) && ofx_aligned16(mean) && ofx_aligned16(rstd), OFX_EALIGN);
+    if (res_mean) OFX_REQUIRE(res && res_rstd, OFX_EINVAL);
+    const long total4 = (long)B * HW * (C / 4);
+    hipStream_t s = (hipStream_t)stream;
+    OfxProfScope prof("inorm_apply", s);
+    hipLaunchKernelGGL(inorm_apply_kernel, dim3((unsigned)std::min<long>((total4 + 255) / 256, 16384)), dim3(256), 0, s, x,
+                       mean, rstd, res, res_mean, res_rstd, out, HW, C, total4, relu);
+    return ofx_launch_status();
+}
+
+int ofx_upsample_flow(const float* coords1, const float* mask, float* flow_up, int B, int h, int w, void* stream) {
+    OFX_REQUIRE(coords1 && mask && flow_up && B > 0 && h > 0 && w > 0, OFX_EINVAL);
+    OFX_REQUIRE((((uintptr_t)coords1) & 7u) == 0 && (((uintptr_t)flow_up) & 7u) == 0, OFX_EALIGN);
+    const long M = (long)B * h * w;
+    hipStream_t s = (hipStream_t)stream;
+    OfxProfScope prof("upsample_flow", s);
+    hipLaunchKernelGGL(upsample_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, s, coords1, mask, flow_up, h, w, M);
+    return ofx_launch_status();
+}
+
+}  // extern "C"

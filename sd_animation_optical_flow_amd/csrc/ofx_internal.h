@@ -1,0 +1,65 @@
+// Internal helpers shared by the HIP translation units of libofx.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+#include "../../include/ofx.h"
+
+#define OFX_HIP_CHECK(expr)                         \
+    do {                                            \
+        hipError_t _e = (expr);                     \
+        if (_e != hipSuccess) return (int)_e;       \
+    } while (0)
+
+#define OFX_REQUIRE(cond, code) \
+    do {                        \
+        if (!(cond)) return (code); \
+    } while (0)
+
+static inline bool ofx_aligned16(const void* p) { return (((uintptr_t)p) & 15u) == 0; }
+static inline int ofx_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+// ---- profiling hooks (prof.cpp) -------------------------------------------------------
+// Usage in a launcher:   OfxProfScope _p("kernel_name", stream);  kernel<<<...>>>(...);
+// The scope records an event pair on `stream` when profiling is enabled and is free otherwise.
+struct OfxProfScope {
+    int slot;
+    hipStream_t stream;
+    OfxProfScope(const char* name, hipStream_t s);
+    ~OfxProfScope();
+};
+
+static inline int ofx_launch_status() {
+    hipError_t e = hipGetLastError();
+    return (int)e;
+}
+
+// conv.hip: ofx_conv2d with an extra scalar multiplier on the accumulator (out = act(acc*alpha*scale + shift))
+extern "C" int ofx_conv2d_alpha(const ofx_conv_desc* d, float alpha, void* stream);
+
+// corr.hip / net_misc.hip: internal launchers used by the RAFT engine
+int ofx_local_corr_launch(const float* f1, const float* f2, const float* coords, float* out, long sb, long sn,
+                          long sc, long sp, int B, int H1, int W1, int H2, int W2, int C, int N, int r, float scale,
+                          float cscale, hipStream_t s);
+int ofx_corr_pool_launch(const float* l0, float* l1, float* l2, float* l3, int B, int h, int w, int levels, hipStream_t s);
+int ofx_init_state(float* coords1, float* flow4, float* hx, int ldh, int flow_off, int B, int h, int w, hipStream_t s);
+int ofx_coords_to_flow(const float* coords1, float* flow, int B, int h, int w, hipStream_t s);
+
+// ---- device helpers --------------------------------------------------------------------
+#ifdef __HIPCC__
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float ofx_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+// Keys cubic weights, A = -0.75 (same polynomial form as OpenCV's interpolateCubic)
+__device__ __forceinline__ void ofx_cubic_coeffs(float t, float w[4]) {
+    const float A = -0.75f;
+    float t1 = t + 1.0f;
+    w[0] = __fsub_rn(__fmul_rn(__fadd_rn(__fmul_rn(__fsub_rn(__fmul_rn(A, t1), 5.0f * A), t1), 8.0f * A), t1), 4.0f * A);
+    w[1] = __fadd_rn(__fmul_rn(__fmul_rn(__fsub_rn(__fmul_rn(A + 2.0f, t), A + 3.0f), t), t), 1.0f);
+    float u = __fsub_rn(1.0f, t);
+    w[2] = __fadd_rn(__fmul_rn(__fmul_rn(__fsub_rn(__fmul_rn(A + 2.0f, u), A + 3.0f), u), u), 1.0f);
+    w[3] = __fsub_rn(__fsub_rn(__fsub_rn(1.0f, w[0]), w[1]), w[2]);
+}
+#endif

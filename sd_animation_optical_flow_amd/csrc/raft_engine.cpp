@@ -1,0 +1,554 @@
+// Native RAFT executor: owns the packed weights on the device and sequences the HIP kernels of one
+// `RAFT.forward(test_mode=True)` (RAFT/core/raft.py:86-144) for a batch of frame pairs.
+//
+// The reference drives ~60 PyTorch ops per refinement iteration from Python; here the whole forward is
+// one C call that enqueues ~15 launches per iteration on the caller's stream, with every activation in
+// a caller-provided HBM workspace (NHWC fp32):
+//
+//   encoders   preprocess -> 7x7/s2 conv -> 3 stages x 2 residual blocks -> 1x1 conv
+//              fnet: instance-norm statistics kernels + norm/ReLU fused into the next conv's A-load
+//              cnet: BatchNorm folded into the conv epilogue (scale/shift), residual add in the epilogue
+//   volume     batched fp32-MFMA GEMM + one pooling kernel (4-level pyramid stays resident in HBM)
+//   iteration  lookup -> convc1 -> convc2 -> convf1 -> convf2 -> conv -> [zr, q] x2 -> flow head (x2)
+//              cat([h, x]) / cat([r*h, x]) / cat([cor, flo]) are channel slices of shared buffers;
+//              GRU gates, h update and coords1 += delta live in conv epilogues
+//   tail       mask head only on the last iteration (the reference evaluates it on every iteration and
+//              discards 19 of 20 results, raft.py:128-139) -> convex upsample -> flow f32[B,H,W,2]
+//
+// Frame<->keyframe batches share one image (OFX_RAFT_SHARED_IMG2): its feature map is computed once
+// and broadcast through a zero batch stride of the correlation GEMM.
+#include "ofx_internal.h"
+
+#include <cmath>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+namespace {
+
+struct ConvW {
+    float* w = nullptr;       // [Cout][Kpad]
+    float* scale = nullptr;   // [Cout] or null
+    float* shift = nullptr;   // [Cout] or null
+    int cout = 0, cin = 0, cin_pad = 0, kh = 0, kw = 0;
+    long kpad = 0;
+};
+
+struct HostTensor {
+    const float* data;
+    int ndim;
+    long shape[4];
+    long numel() const {
+        long n = 1;
+        for (int i = 0; i < ndim; ++i) n *= shape[i];
+        return n;
+    }
+};
+
+constexpr int HD = 128;      // hidden dim (raft.py:38)
+constexpr int CD = 128;      // context dim (raft.py:39)
+constexpr int FD = 256;      // feature dim (raft.py:54)
+constexpr int LEVELS = 4, RADIUS = 4, CORR_CH = LEVELS * (2 * RADIUS + 1) * (2 * RADIUS + 1);   // 324
+constexpr int HX_LD = HD + CD + 128;   // [h | inp | motion(126) | flow(2)] = 384
+constexpr int FLOW_OFF = HX_LD - 2;
+constexpr int ENC_CHUNK = 16;          // images per encoder pass (bounds the activation workspace)
+
+struct Carver {
+    char* base;
+    size_t off = 0, cap;
+    Carver(void* b, size_t c) : base((char*)b), cap(c) {}
+    float* take(size_t nfloats) {
+        size_t bytes = ((nfloats * sizeof(float) + 255) / 256) * 256;
+        char* p = base ? base + off : nullptr;
+        off += bytes;
+        return (float*)p;
+    }
+};
+
+}  // namespace
+
+struct ofx_raft {
+    std::map<std::string, ConvW> convs;
+    std::vector<void*> allocs;
+    std::map<std::string, std::pair<void*, size_t>> bufs;
+    float** d_pyr_table = nullptr;
+};
+
+namespace {
+
+int upload(ofx_raft* r, const std::vector<float>& h, float** d) {
+    OFX_HIP_CHECK(hipMalloc((void**)d, h.size() * sizeof(float)));
+    r->allocs.push_back(*d);
+    OFX_HIP_CHECK(hipMemcpy(*d, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice));
+    return 0;
+}
+
+const HostTensor* find(const std::map<std::string, HostTensor>& sd, const std::string& k) {
+    auto it = sd.find(k);
+    return it == sd.end() ? nullptr : &it->second;
+}
+
+// pack one conv (optionally with an eval-mode BatchNorm folded into scale/shift, optionally an
+// extra output scale as in `.25 * self.mask(net)`, update.py:135)
+int add_conv(ofx_raft* r, const std::map<std::string, HostTensor>& sd, const std::string& name,
+             const std::string& store_as, int cin_pad, const std::string& bn, float out_scale,
+             std::vector<float>* append_w = nullptr, std::vector<float>* append_shift = nullptr) {
+    const HostTensor* w = find(sd, name + ".weight");
+    const HostTensor* b = find(sd, name + ".bias");
+    if (!w || !b || w->ndim != 4 || b->ndim != 1 || b->shape[0] != w->shape[0]) return OFX_EKEY;
+    ConvW c;
+    c.cout = (int)w->shape[0];
+    c.cin = (int)w->shape[1];
+    c.kh = (int)w->shape[2];
+    c.kw = (int)w->shape[3];
+    c.cin_pad = cin_pad > 0 ? cin_pad : ((c.cin + 3) / 4) * 4;
+    if (c.cin_pad < c.cin) return OFX_EKEY;
+    c.kpad = ofx_pack_conv_weight(nullptr, c.cout, c.cin, c.kh, c.kw, c.cin_pad, nullptr);
+    if (c.kpad < 0) return (int)c.kpad;
+    std::vector<float> pw((size_t)c.cout * c.kpad);
+    ofx_pack_conv_weight(w->data, c.cout, c.cin, c.kh, c.kw, c.cin_pad, pw.data());
+    std::vector<float> scale, shift(c.cout);
+    if (!bn.empty()) {
+        const HostTensor* g = find(sd, bn + ".weight");
+        const HostTensor* be = find(sd, bn + ".bias");
+        const HostTensor* rm = find(sd, bn + ".running_mean");
+        const HostTensor* rv = find(sd, bn + ".running_var");
+        if (!g || !be || !rm || !rv) return OFX_EKEY;
+        if (g->numel() != c.cout || be->numel() != c.cout || rm->numel() != c.cout || rv->numel() != c.cout) return OFX_EKEY;
+        scale.resize(c.cout);
+        for (int i = 0; i < c.cout; ++i) {
+            // F.batch_norm(eval): (x - mean) / sqrt(var + eps) * gamma + beta with x = conv + bias
+            const double sc = (double)g->data[i] / std::sqrt((double)rv->data[i] + 1e-5);
+            scale[i] = (float)sc;
+            shift[i] = (float)(((double)b->data[i] - (double)rm->data[i]) * sc + (double)be->data[i]);
+        }
+    } else if (out_scale != 1.0f) {
+        scale.assign(c.cout, out_scale);
+        for (int i = 0; i < c.cout; ++i) shift[i] = b->data[i] * out_scale;
+    } else {
+        for (int i = 0; i < c.cout; ++i) shift[i] = b->data[i];
+    }
+    if (append_w) {   // caller concatenates several convs along Cout (GRU z|r)
+        append_w->insert(append_w->end(), pw.begin(), pw.end());
+        append_shift->insert(append_shift->end(), shift.begin(), shift.end());
+        c.w = nullptr;
+        r->convs[store_as] = c;
+        return 0;
+    }
+    int st = upload(r, pw, &c.w);
+    if (st) return st;
+    st = upload(r, shift, &c.shift);
+    if (st) return st;
+    if (!scale.empty()) {
+        st = upload(r, scale, &c.scale);
+        if (st) return st;
+    }
+    r->convs[store_as] = c;
+    return 0;
+}
+
+int build_encoder(ofx_raft* r, const std::map<std::string, HostTensor>& sd, const std::string& enc, bool bn) {
+    auto B = [&](const std::string& n) { return bn ? enc + "." + n : std::string(); };
+    int st = add_conv(r, sd, enc + ".conv1", enc + ".conv1", 4, B("norm1"), 1.f);
+    if (st) return st;
+    for (int li = 1; li <= 3; ++li) {
+        for (int bi = 0; bi < 2; ++bi) {
+            const std::string p = enc + ".layer" + std::to_string(li) + "." + std::to_string(bi);
+            const std::string pb = "layer" + std::to_string(li) + "." + std::to_string(bi);
+            st = add_conv(r, sd, p + ".conv1", p + ".conv1", 0, B(pb + ".norm1"), 1.f);
+            if (st) return st;
+            st = add_conv(r, sd, p + ".conv2", p + ".conv2", 0, B(pb + ".norm2"), 1.f);
+            if (st) return st;
+            if (li > 1 && bi == 0) {
+                st = add_conv(r, sd, p + ".downsample.0", p + ".down", 0, B(pb + ".norm3"), 1.f);
+                if (st) return st;
+            }
+        }
+    }
+    return add_conv(r, sd, enc + ".conv2", enc + ".conv2", 0, "", 1.f);
+}
+
+int build_gru(ofx_raft* r, const std::map<std::string, HostTensor>& sd, const std::string& tag) {
+    // z and r share their input: one conv with Cout = 256 ([convz ; convr] rows)
+    std::vector<float> w, sh;
+    int st = add_conv(r, sd, "update_block.gru.convz" + tag, "gru.z" + tag, 0, "", 1.f, &w, &sh);
+    if (st) return st;
+    st = add_conv(r, sd, "update_block.gru.convr" + tag, "gru.r" + tag, 0, "", 1.f, &w, &sh);
+    if (st) return st;
+    ConvW c = r->convs["gru.z" + tag];
+    c.cout *= 2;
+    st = upload(r, w, &c.w);
+    if (st) return st;
+    st = upload(r, sh, &c.shift);
+    if (st) return st;
+    r->convs["gru.zr" + tag] = c;
+    return add_conv(r, sd, "update_block.gru.convq" + tag, "gru.q" + tag, 0, "", 1.f);
+}
+
+struct Launcher {
+    hipStream_t s;
+    int st = 0;
+    // generic conv launch; all pointer plumbing in one place
+    void conv(const ConvW& c, const float* in0, int ld0, int c0, const float* in1, int ld1, int c1, float* out, int ldo,
+              int B, int Hin, int Win, int stride, int act, int epi = OFX_EPI_PLAIN, const float* res = nullptr,
+              int ldres = 0, const float* nmean = nullptr, const float* nrstd = nullptr, float* aux_z = nullptr,
+              float* aux_rh = nullptr, float* aux_h = nullptr, int ldh = 0, float* aux_coords = nullptr,
+              float* aux_flow4 = nullptr, int row_off = 0, int rows = 0) {
+        if (st) return;
+        ofx_conv_desc d{};
+        d.in0 = in0; d.ld0 = ld0; d.c0 = c0;
+        d.in1 = in1; d.ld1 = ld1; d.c1 = c1;
+        const int cout = rows ? rows : c.cout;
+        d.w = c.w + (long)row_off * c.kpad;
+        d.scale = c.scale ? c.scale + row_off : nullptr;
+        d.shift = c.shift ? c.shift + row_off : nullptr;
+        d.out = out; d.ldo = ldo;
+        d.res = res; d.ldres = ldres;
+        d.nmean = nmean; d.nrstd = nrstd;
+        d.aux_z = aux_z; d.aux_rh = aux_rh; d.aux_h = aux_h; d.ldh = ldh;
+        d.aux_coords = aux_coords; d.aux_flow4 = aux_flow4;
+        d.B = B; d.Hin = Hin; d.Win = Win;
+        const int padH = c.kh / 2, padW = c.kw / 2;
+        d.Hout = (Hin + 2 * padH - c.kh) / stride + 1;
+        d.Wout = (Win + 2 * padW - c.kw) / stride + 1;
+        d.Cout = cout; d.KH = c.kh; d.KW = c.kw; d.stride = stride; d.padH = padH; d.padW = padW;
+        d.act = act; d.epi = epi;
+        if (c0 + c1 != c.cin_pad) { st = OFX_EKEY; return; }
+        st = ofx_conv2d(&d, s);
+    }
+};
+
+struct EncBufs {
+    float *x0, *X, *Y, *R1, *R2, *R3;
+    float* stats;     // 6 x [chunk][128] floats (mean/rstd for up to 3 norms)
+    float* scratch;   // inorm partial sums
+};
+
+}  // namespace
+
+// --------------------------------------------------------------------------------------------
+static int run_encoder(ofx_raft* r, const std::string& enc, bool bn, const uint8_t* imgs, int n, int H, int W,
+                       int bgr, const EncBufs& eb, float* out, int out_ld, bool split_tanh_relu, hipStream_t s) {
+    // `out`: [n*h*w][out_ld]; fnet writes 256 channels; cnet writes tanh(0:128) | relu(128:256)
+    Launcher L{s};
+    const int H2 = H / 2, W2 = W / 2, H4 = H / 4, W4 = W / 4, H8 = H / 8, W8 = W / 8;
+    const int SC = ENC_CHUNK * 128;   // floats per stats vector slot
+    float* m1 = eb.stats + 0 * SC; float* s1 = eb.stats + 1 * SC;
+    float* m2 = eb.stats + 2 * SC; float* s2 = eb.stats + 3 * SC;
+    float* m3 = eb.stats + 4 * SC; float* s3 = eb.stats + 5 * SC;
+    auto C = [&](const std::string& k) -> const ConvW& { return r->convs[enc + "." + k]; };
+    int st = ofx_preprocess_u8(imgs, eb.x0, (long)n * H * W, bgr, s);
+    if (st) return st;
+    auto stats = [&](const float* x, long HW, int ch, float* mean, float* rstd) {
+        if (L.st) return;
+        L.st = ofx_inorm_stats(x, ch, mean, rstd, eb.scratch, n, HW, ch, 1e-5f, s);
+    };
+    float* X = eb.X;
+    float* Y = eb.Y;
+    if (!bn) {
+        L.conv(C("conv1"), eb.x0, 4, 4, nullptr, 0, 0, eb.R1, 64, n, H, W, 2, OFX_ACT_NONE);
+        stats(eb.R1, (long)H2 * W2, 64, m1, s1);
+        if (!L.st) L.st = ofx_inorm_apply(eb.R1, m1, s1, nullptr, nullptr, nullptr, X, n, (long)H2 * W2, 64, 1, s);
+    } else {
+        L.conv(C("conv1"), eb.x0, 4, 4, nullptr, 0, 0, X, 64, n, H, W, 2, OFX_ACT_RELU);
+    }
+    int hin = H2, win = W2, cin = 64;
+    const int dims[3] = {64, 96, 128};
+    for (int li = 1; li <= 3; ++li) {
+        const int dim = dims[li - 1];
+        for (int bi = 0; bi < 2; ++bi) {
+            const int stride = (li > 1 && bi == 0) ? 2 : 1;
+            const int ho = hin / stride, wo = win / stride;
+            const std::string p = "layer" + std::to_string(li) + "." + std::to_string(bi);
+            if (!bn) {
+                L.conv(C(p + ".conv1"), X, cin, cin, nullptr, 0, 0, eb.R1, dim, n, hin, win, stride, OFX_ACT_NONE);
+                stats(eb.R1, (long)ho * wo, dim, m1, s1);
+                // norm1 + ReLU fused into conv2's operand load
+                L.conv(C(p + ".conv2"), eb.R1, dim, dim, nullptr, 0, 0, eb.R2, dim, n, ho, wo, 1, OFX_ACT_NONE,
+                       OFX_EPI_PLAIN, nullptr, 0, m1, s1);
+                stats(eb.R2, (long)ho * wo, dim, m2, s2);
+                if (stride == 2) {
+                    L.conv(C(p + ".down"), X, cin, cin, nullptr, 0, 0, eb.R3, dim, n, hin, win, 2, OFX_ACT_NONE);
+                    stats(eb.R3, (long)ho * wo, dim, m3, s3);
+                    if (!L.st) L.st = ofx_inorm_apply(eb.R2, m2, s2, eb.R3, m3, s3, Y, n, (long)ho * wo, dim, 1, s);
+                } else {
+                    if (!L.st) L.st = ofx_inorm_apply(eb.R2, m2, s2, X, nullptr, nullptr, Y, n, (long)ho * wo, dim, 1, s);
+                }
+            } else {
+                L.conv(C(p + ".conv1"), X, cin, cin, nullptr, 0, 0, eb.R1, dim, n, hin, win, stride, OFX_ACT_RELU);
+                const float* res = X;
+                if (stride == 2) {
+                    L.conv(C(p + ".down"), X, cin, cin, nullptr, 0, 0, eb.R3, dim, n, hin, win, 2, OFX_ACT_NONE);
+                    res = eb.R3;
+                }
+                L.conv(C(p + ".conv2"), eb.R1, dim, dim, nullptr, 0, 0, Y, dim, n, ho, wo, 1, OFX_ACT_RELU, OFX_EPI_PLAIN,
+                       res, dim);
+            }
+            std::swap(X, Y);
+            hin = ho; win = wo; cin = dim;
+        }
+    }
+    (void)H4; (void)W4; (void)H8; (void)W8;
+    if (!split_tanh_relu) {
+        L.conv(C("conv2"), X, 128, 128, nullptr, 0, 0, out, out_ld, n, hin, win, 1, OFX_ACT_NONE);
+    } else {
+        // net = tanh(cnet[:, :128]), inp = relu(cnet[:, 128:256])  (raft.py:111-114)
+        L.conv(C("conv2"), X, 128, 128, nullptr, 0, 0, out, out_ld, n, hin, win, 1, OFX_ACT_TANH, OFX_EPI_PLAIN, nullptr, 0,
+               nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr, 0, HD);
+        L.conv(C("conv2"), X, 128, 128, nullptr, 0, 0, out + HD, out_ld, n, hin, win, 1, OFX_ACT_RELU, OFX_EPI_PLAIN, nullptr,
+               0, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr, HD, CD);
+    }
+    return L.st;
+}
+
+// workspace layout shared by the size query and the forward
+struct RaftWs {
+    EncBufs eb;
+    float *fmap1, *fmap2, *f2l[LEVELS];
+    float* pyr[LEVELS];
+    float *hx, *coords1, *flow4, *corr, *c1, *corflo, *f1, *z, *rh, *mask;
+    size_t bytes;
+};
+
+static RaftWs carve(void* base, size_t cap, int B, int H, int W, int flags) {
+    RaftWs w{};
+    Carver c(base, cap);
+    const int h = H / 8, wd = W / 8;
+    const long N = (long)h * wd;
+    const long M = (long)B * N;
+    const int nch = ENC_CHUNK < 2 * B ? ENC_CHUNK : 2 * B;
+    const long half = (long)(H / 2) * (W / 2) * 64;
+    w.eb.x0 = c.take((size_t)nch * H * W * 4);
+    w.eb.X = c.take((size_t)nch * half);
+    w.eb.Y = c.take((size_t)nch * half);
+    w.eb.R1 = c.take((size_t)nch * half);
+    w.eb.R2 = c.take((size_t)nch * half);
+    w.eb.R3 = c.take((size_t)nch * (H / 4) * (W / 4) * 96);
+    w.eb.stats = c.take((size_t)6 * ENC_CHUNK * 128);
+    w.eb.scratch = c.take((size_t)ENC_CHUNK * 64 * 128 * 2 * 2);   // doubles: chunk x slices x C x {sum, sumsq}
+    const long n1 = (flags & OFX_RAFT_SHARED_IMG1) ? 1 : B, n2 = (flags & OFX_RAFT_SHARED_IMG2) ? 1 : B;
+    w.fmap1 = c.take((size_t)n1 * N * FD);
+    w.fmap2 = c.take((size_t)n2 * N * FD);
+    if (flags & OFX_RAFT_ALT_CORR) {
+        w.f2l[0] = w.fmap2;
+        for (int l = 1; l < LEVELS; ++l) w.f2l[l] = c.take((size_t)n2 * (h >> l) * (wd >> l) * FD);
+    } else {
+        for (int l = 0; l < LEVELS; ++l) w.pyr[l] = c.take((size_t)M * (h >> l) * (wd >> l));
+    }
+    w.hx = c.take((size_t)M * HX_LD);
+    w.coords1 = c.take((size_t)M * 2);
+    w.flow4 = c.take((size_t)M * 4);
+    w.corr = c.take((size_t)M * CORR_CH);
+    w.c1 = c.take((size_t)M * 256);
+    w.corflo = c.take((size_t)M * 256);
+    w.f1 = c.take((size_t)M * 128);
+    w.z = c.take((size_t)M * HD);
+    w.rh = c.take((size_t)M * HD);
+    w.mask = c.take((size_t)M * 576);
+    w.bytes = c.off;
+    return w;
+}
+
+extern "C" {
+
+int ofx_raft_create(const ofx_tensor* tensors, int n, ofx_raft** out) {
+    OFX_REQUIRE(tensors && n > 0 && out, OFX_EINVAL);
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return OFX_ENODEV;
+    std::map<std::string, HostTensor> sd;
+    for (int i = 0; i < n; ++i) {
+        if (!tensors[i].name || !tensors[i].data) continue;
+        std::string k = tensors[i].name;
+        if (k.rfind("module.", 0) == 0) k = k.substr(7);
+        HostTensor t;
+        t.data = tensors[i].data;
+        t.ndim = tensors[i].ndim;
+        for (int j = 0; j < 4; ++j) t.shape[j] = j < t.ndim ? tensors[i].shape[j] : 1;
+        sd[k] = t;
+    }
+    ofx_raft* r = new ofx_raft();
+    int st = build_encoder(r, sd, "fnet", false);
+    if (!st) st = build_encoder(r, sd, "cnet", true);
+    const char* ub = "update_block.";
+    if (!st) st = add_conv(r, sd, std::string(ub) + "encoder.convc1", "convc1", 0, "", 1.f);
+    if (!st) st = add_conv(r, sd, std::string(ub) + "encoder.convc2", "convc2", 0, "", 1.f);
+    if (!st) st = add_conv(r, sd, std::string(ub) + "encoder.convf1", "convf1", 4, "", 1.f);
+    if (!st) st = add_conv(r, sd, std::string(ub) + "encoder.convf2", "convf2", 0, "", 1.f);
+    if (!st) st = add_conv(r, sd, std::string(ub) + "encoder.conv", "conv", 0, "", 1.f);
+    if (!st) st = build_gru(r, sd, "1");
+    if (!st) st = build_gru(r, sd, "2");
+    if (!st) st = add_conv(r, sd, std::string(ub) + "flow_head.conv1", "fh1", 0, "", 1.f);
+    if (!st) st = add_conv(r, sd, std::string(ub) + "flow_head.conv2", "fh2", 0, "", 1.f);
+    if (!st) st = add_conv(r, sd, std::string(ub) + "mask.0", "mask0", 0, "", 1.f);
+    if (!st) st = add_conv(r, sd, std::string(ub) + "mask.2", "mask2", 0, "", 0.25f);
+    if (!st) {
+        hipError_t e = hipMalloc((void**)&r->d_pyr_table, sizeof(float*) * LEVELS);
+        if (e != hipSuccess) st = (int)e;
+    }
+    if (st) {
+        ofx_raft_destroy(r);
+        return st;
+    }
+    *out = r;
+    return 0;
+}
+
+int ofx_raft_destroy(ofx_raft* r) {
+    if (!r) return 0;
+    for (void* p : r->allocs) (void)hipFree(p);
+    if (r->d_pyr_table) (void)hipFree(r->d_pyr_table);
+    delete r;
+    return 0;
+}
+
+size_t ofx_raft_workspace_bytes(const ofx_raft* r, int B, int H, int W) {
+    (void)r;
+    if (B <= 0 || H <= 0 || W <= 0 || (H % 8) || (W % 8)) return 0;
+    // the volume layout is the larger of the two correlation modes
+    size_t a = carve(nullptr, 0, B, H, W, 0).bytes;
+    size_t b = carve(nullptr, 0, B, H, W, OFX_RAFT_ALT_CORR).bytes;
+    return a > b ? a : b;
+}
+
+int ofx_raft_forward(ofx_raft* r, const uint8_t* image1, const uint8_t* image2, int B, int H, int W, int iters,
+                     int flags, float* flow_up, float* flow_low, void* workspace, size_t workspace_bytes, void* stream) {
+    OFX_REQUIRE(r && image1 && image2 && flow_up && workspace, OFX_EINVAL);
+    OFX_REQUIRE(B > 0 && H >= 64 && W >= 64 && (H % 8) == 0 && (W % 8) == 0 && iters >= 1, OFX_EINVAL);
+    OFX_REQUIRE((((uintptr_t)workspace) & 255u) == 0, OFX_EALIGN);
+    RaftWs ws = carve(workspace, workspace_bytes, B, H, W, flags);
+    OFX_REQUIRE(ws.bytes <= workspace_bytes, OFX_ENOMEM);
+    hipStream_t s = (hipStream_t)stream;
+    const int h = H / 8, w = W / 8;
+    const long N = (long)h * w;
+    const long M = (long)B * N;
+    const int bgr = (flags & OFX_RAFT_BGR) ? 1 : 0;
+    const bool sh1 = flags & OFX_RAFT_SHARED_IMG1, sh2 = flags & OFX_RAFT_SHARED_IMG2;
+    const bool alt = flags & OFX_RAFT_ALT_CORR;
+    const long img_bytes = (long)H * W * 3;
+
+    // ---- feature encoders (instance norm => per-image statistics, so chunking is exact)
+    int st = 0;
+    const int n1 = sh1 ? 1 : B, n2 = sh2 ? 1 : B;
+    for (int i0 = 0; i0 < n1 && !st; i0 += ENC_CHUNK) {
+        const int n = std::min(ENC_CHUNK, n1 - i0);
+        st = run_encoder(r, "fnet", false, image1 + i0 * img_bytes, n, H, W, bgr, ws.eb, ws.fmap1 + (long)i0 * N * FD, FD,
+                         false, s);
+    }
+    for (int i0 = 0; i0 < n2 && !st; i0 += ENC_CHUNK) {
+        const int n = std::min(ENC_CHUNK, n2 - i0);
+        st = run_encoder(r, "fnet", false, image2 + i0 * img_bytes, n, H, W, bgr, ws.eb, ws.fmap2 + (long)i0 * N * FD, FD,
+                         false, s);
+    }
+    // ---- context encoder on image1 -> hx[:, 0:128] = tanh, hx[:, 128:256] = relu
+    if (sh1) {
+        if (!st) st = run_encoder(r, "cnet", true, image1, 1, H, W, bgr, ws.eb, ws.hx, HX_LD, true, s);
+        for (int k = 1; k < B && !st; ++k)   // one shared image1: replicate its context rows
+            OFX_HIP_CHECK(hipMemcpy2DAsync(ws.hx + (long)k * N * HX_LD, HX_LD * sizeof(float), ws.hx, HX_LD * sizeof(float),
+                                           (HD + CD) * sizeof(float), (size_t)N, hipMemcpyDeviceToDevice, s));
+    } else {
+        for (int i0 = 0; i0 < B && !st; i0 += ENC_CHUNK) {
+            const int n = std::min(ENC_CHUNK, B - i0);
+            st = run_encoder(r, "cnet", true, image1 + i0 * img_bytes, n, H, W, bgr, ws.eb, ws.hx + (long)i0 * N * HX_LD,
+                             HX_LD, true, s);
+        }
+    }
+    if (st) return st;
+
+    // ---- correlation
+    if (!alt) {
+        ofx_conv_desc d{};
+        d.in0 = ws.fmap1; d.ld0 = FD; d.c0 = FD;
+        d.w = ws.fmap2;
+        d.out = ws.pyr[0]; d.ldo = (int)N;
+        d.nz = B; d.a_zs = sh1 ? 0 : N * FD; d.w_zs = sh2 ? 0 : N * FD; d.o_zs = N * N;
+        d.B = 1; d.Hin = h; d.Win = w; d.Hout = h; d.Wout = w; d.Cout = (int)N;
+        d.KH = 1; d.KW = 1; d.stride = 1;
+        d.act = OFX_ACT_NONE; d.epi = OFX_EPI_PLAIN;
+        // zero batch strides broadcast a shared key-frame feature map across the batch
+        st = ofx_conv2d_alpha(&d, 1.0f / std::sqrt((float)FD), s);
+        if (!st) st = ofx_corr_pool_launch(ws.pyr[0], ws.pyr[1], ws.pyr[2], ws.pyr[3], B, h, w, LEVELS, s);
+        if (st) return st;
+    } else {
+        for (int l = 1; l < LEVELS && !st; ++l)
+            st = ofx_avgpool2_nhwc(ws.f2l[l - 1], ws.f2l[l], n2, h >> (l - 1), w >> (l - 1), FD, s);
+        if (st) return st;
+    }
+
+    st = ofx_init_state(ws.coords1, ws.flow4, ws.hx, HX_LD, FLOW_OFF, B, h, w, s);
+    if (st) return st;
+
+    Launcher L{s};
+    auto C = [&](const char* k) -> const ConvW& { return r->convs[k]; };
+    const float* pyr_c[LEVELS] = {ws.pyr[0], ws.pyr[1], ws.pyr[2], ws.pyr[3]};
+    const int rd2 = (2 * RADIUS + 1) * (2 * RADIUS + 1);
+    for (int it = 0; it < iters && !L.st; ++it) {
+        // correlation features at the current estimate
+        if (!alt) {
+            L.st = ofx_corr_lookup(pyr_c, ws.coords1, ws.corr, CORR_CH, B, h, w, LEVELS, RADIUS, s);
+        } else {
+            for (int l = 0; l < LEVELS && !L.st; ++l) {
+                if (sh1 || sh2) { L.st = OFX_EINVAL; break; }   // alt-corr path: per-pair feature maps only
+                L.st = ofx_local_corr_launch(ws.fmap1, ws.f2l[l], ws.coords1, ws.corr + (long)l * rd2, N * CORR_CH, 0, 1,
+                                             CORR_CH, B, h, w, h >> l, w >> l, FD, 1, RADIUS, 1.0f / std::sqrt((float)FD),
+                                             1.0f / (float)(1 << l), s);
+            }
+        }
+        // motion encoder (update.py:88-97)
+        L.conv(C("convc1"), ws.corr, CORR_CH, CORR_CH, nullptr, 0, 0, ws.c1, 256, B, h, w, 1, OFX_ACT_RELU);
+        L.conv(C("convc2"), ws.c1, 256, 256, nullptr, 0, 0, ws.corflo, 256, B, h, w, 1, OFX_ACT_RELU);
+        L.conv(C("convf1"), ws.flow4, 4, 4, nullptr, 0, 0, ws.f1, 128, B, h, w, 1, OFX_ACT_RELU);
+        L.conv(C("convf2"), ws.f1, 128, 128, nullptr, 0, 0, ws.corflo + 192, 256, B, h, w, 1, OFX_ACT_RELU);
+        L.conv(C("conv"), ws.corflo, 256, 256, nullptr, 0, 0, ws.hx + HD + CD, HX_LD, B, h, w, 1, OFX_ACT_RELU);
+        // SepConvGRU (update.py:44-60): horizontal then vertical pass
+        for (int pass = 1; pass <= 2; ++pass) {
+            const char* zr = pass == 1 ? "gru.zr1" : "gru.zr2";
+            const char* q = pass == 1 ? "gru.q1" : "gru.q2";
+            L.conv(C(zr), ws.hx, HX_LD, HX_LD, nullptr, 0, 0, nullptr, 0, B, h, w, 1, OFX_ACT_NONE, OFX_EPI_GRU_ZR, nullptr, 0,
+                   nullptr, nullptr, ws.z, ws.rh, ws.hx, HX_LD);
+            L.conv(C(q), ws.rh, HD, HD, ws.hx + HD, HX_LD, HX_LD - HD, nullptr, 0, B, h, w, 1, OFX_ACT_NONE, OFX_EPI_GRU_Q,
+                   nullptr, 0, nullptr, nullptr, ws.z, nullptr, ws.hx, HX_LD);
+        }
+        // flow head (update.py:6-14) + coords1 += delta (raft.py:131) in the epilogue
+        L.conv(C("fh1"), ws.hx, HX_LD, HD, nullptr, 0, 0, ws.c1, 256, B, h, w, 1, OFX_ACT_RELU);
+        L.conv(C("fh2"), ws.c1, 256, 256, nullptr, 0, 0, nullptr, 0, B, h, w, 1, OFX_ACT_NONE, OFX_EPI_FLOW, nullptr, 0,
+               nullptr, nullptr, nullptr, nullptr, ws.hx + FLOW_OFF, HX_LD, ws.coords1, ws.flow4);
+    }
+    // mask head (update.py:122-125,135) on the final hidden state, then convex upsample
+    L.conv(C("mask0"), ws.hx, HX_LD, HD, nullptr, 0, 0, ws.c1, 256, B, h, w, 1, OFX_ACT_RELU);
+    L.conv(C("mask2"), ws.c1, 256, 256, nullptr, 0, 0, ws.mask, 576, B, h, w, 1, OFX_ACT_NONE);
+    if (L.st) return L.st;
+    st = ofx_upsample_flow(ws.coords1, ws.mask, flow_up, B, h, w, s);
+    if (st) return st;
+    if (flow_low) {
+        st = ofx_coords_to_flow(ws.coords1, flow_low, B, h, w, s);
+        if (st) return st;
+    }
+
+    r->bufs.clear();
+    auto reg = [&](const char* k, float* p, size_t nf) { r->bufs[k] = std::make_pair((void*)p, nf); };
+    reg("fmap1", ws.fmap1, (size_t)n1 * N * FD);
+    reg("fmap2", ws.fmap2, (size_t)n2 * N * FD);
+    reg("hx", ws.hx, (size_t)M * HX_LD);
+    reg("coords1", ws.coords1, (size_t)M * 2);
+    reg("corr", ws.corr, (size_t)M * CORR_CH);
+    reg("mask", ws.mask, (size_t)M * 576);
+    if (!alt)
+        for (int l = 0; l < LEVELS; ++l) {
+            char nm[8];
+            snprintf(nm, sizeof nm, "pyr%d", l);
+            reg(nm, ws.pyr[l], (size_t)M * (h >> l) * (w >> l));
+        }
+    return 0;
+}
+
+int ofx_raft_buffer(const ofx_raft* r, const char* name, void** ptr, size_t* nfloats) {
+    OFX_REQUIRE(r && name && ptr && nfloats, OFX_EINVAL);
+    auto it = r->bufs.find(name);
+    if (it == r->bufs.end()) return OFX_EKEY;
+    *ptr = it->second.first;
+    *nfloats = it->second.second;
+    return 0;
+}
+
+}  // extern "C"

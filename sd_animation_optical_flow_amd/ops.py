@@ -1,0 +1,350 @@
+"""Device operators: thin torch-tensor wrappers over the C ABI of libofx.so.
+
+PyTorch is plumbing here (device memory + the current HIP stream); every byte of arithmetic happens
+in the hand-written HIP kernels.  Preconditions mirror the reference's extension
+(`RAFT/alt_cuda_corr/correlation.cpp:19-21`): tensors must be on the GPU and contiguous, otherwise a
+RuntimeError is raised -- nothing silently falls back to the CPU.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import json
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import ConvDesc, check
+
+WARP_MODES = {"bilinear": 0, "bicubic": 1, "cv2_cubic": 2}
+ACTS = {None: 0, "none": 0, "relu": 1, "sigmoid": 2, "tanh": 3}
+EPI_PLAIN, EPI_GRU_ZR, EPI_GRU_Q, EPI_FLOW = 0, 1, 2, 3
+
+
+def _stream() -> C.c_void_p:
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _chk(t: torch.Tensor, name: str, dtype=None) -> torch.Tensor:
+    if not isinstance(t, torch.Tensor):
+        raise RuntimeError(f"{name} must be a torch.Tensor")
+    if not t.is_cuda:
+        raise RuntimeError(f"{name} must be a CUDA tensor")       # correlation.cpp:19
+    if not t.is_contiguous():
+        raise RuntimeError(f"{name} must be contiguous")          # correlation.cpp:20
+    if dtype is not None and t.dtype != dtype:
+        raise RuntimeError(f"{name} must be {dtype}, got {t.dtype}")
+    return t
+
+
+def _ptr(t: Optional[torch.Tensor]) -> C.c_void_p:
+    return C.c_void_p(0 if t is None else t.data_ptr())
+
+
+# --------------------------------------------------------------------------------------
+# profiling
+# --------------------------------------------------------------------------------------
+def prof_enable(on: bool) -> None:
+    check(_lib.lib().ofx_prof_enable(1 if on else 0), "ofx_prof_enable")
+
+
+def prof_collect() -> dict:
+    buf = C.create_string_buffer(1 << 16)
+    check(_lib.lib().ofx_prof_collect(buf, len(buf)), "ofx_prof_collect")
+    return json.loads(buf.value.decode())
+
+
+# --------------------------------------------------------------------------------------
+# warp
+# --------------------------------------------------------------------------------------
+def warp(frame: torch.Tensor, flow: torch.Tensor, mode: str = "bilinear", sign: float = 1.0) -> torch.Tensor:
+    """frame [H,W,C] (one frame shared by all flows) or [B,H,W,C], uint8 or float32;
+    flow f32 [B,H,W,2] or [H,W,2].  Returns the warped frames, [B,H,W,C] (or [H,W,C])."""
+    squeeze = flow.dim() == 3
+    fl = _chk(flow if not squeeze else flow[None], "flow", torch.float32)
+    B, H, W, _ = fl.shape
+    if frame.dim() == 2:
+        raise RuntimeError("frame must be HWC; add a channel axis")
+    shared = frame.dim() == 3
+    fr = _chk(frame, "frame")
+    Cn = fr.shape[-1]
+    if tuple(fr.shape[-3:-1]) != (H, W) or (not shared and fr.shape[0] != B):
+        raise RuntimeError(f"frame {tuple(fr.shape)} does not match flow {tuple(fl.shape)}")
+    out = torch.empty((B, H, W, Cn), dtype=fr.dtype, device=fr.device)
+    stride = 0 if shared else H * W * Cn
+    L = _lib.lib()
+    if fr.dtype == torch.uint8:
+        fn, nm = L.ofx_warp_u8, "ofx_warp_u8"
+    elif fr.dtype == torch.float32:
+        fn, nm = L.ofx_warp_f32, "ofx_warp_f32"
+    else:
+        raise RuntimeError(f"warp: unsupported dtype {fr.dtype}")
+    check(fn(_ptr(fr), stride, _ptr(fl), _ptr(out), B, H, W, Cn, WARP_MODES[mode], float(sign), _stream()), nm)
+    return out[0] if (squeeze and shared) else out
+
+
+def resize_cubic(img: torch.Tensor, out_h: int, out_w: int) -> torch.Tensor:
+    """f32 [B,H,W,C] -> [B,out_h,out_w,C], cv2.resize(INTER_CUBIC) semantics."""
+    x = _chk(img, "img", torch.float32)
+    B, H, W, Cn = x.shape
+    out = torch.empty((B, out_h, out_w, Cn), dtype=torch.float32, device=x.device)
+    check(_lib.lib().ofx_resize_cubic_f32(_ptr(x), _ptr(out), B, H, W, out_h, out_w, Cn, _stream()), "ofx_resize_cubic_f32")
+    return out
+
+
+# --------------------------------------------------------------------------------------
+# masks
+# --------------------------------------------------------------------------------------
+def generate_mask(conf: torch.Tensor, log_conf: Optional[torch.Tensor] = None, thres: float = 0.8,
+                  ksize: int = 7, cmp_gt: bool = False) -> torch.Tensor:
+    """conf f32 [B,H,W]; log_conf (optional, modified IN PLACE like the reference). -> uint8 [B,H,W]."""
+    c = _chk(conf, "confidence", torch.float32)
+    B, H, W = c.shape
+    if log_conf is not None:
+        _chk(log_conf, "log_confidence", torch.float32)
+    out = torch.empty((B, H, W), dtype=torch.uint8, device=c.device)
+    check(_lib.lib().ofx_generate_mask(_ptr(c), _ptr(log_conf), _ptr(out), B, H, W, float(thres), int(ksize),
+                                       1 if cmp_gt else 0, _stream()), "ofx_generate_mask")
+    return out
+
+
+def dilate(mask: torch.Tensor, ksize: int) -> torch.Tensor:
+    m = _chk(mask, "mask", torch.uint8)
+    B, H, W = m.shape
+    out = torch.empty_like(m)
+    check(_lib.lib().ofx_dilate_u8(_ptr(m), _ptr(out), B, H, W, int(ksize), _stream()), "ofx_dilate_u8")
+    return out
+
+
+def expand_mask(mask: torch.Tensor, image_bgr: torch.Tensor, edge_thres: int = 20, ksize: int = 7) -> torch.Tensor:
+    m = _chk(mask, "mask", torch.uint8)
+    img = _chk(image_bgr, "image", torch.uint8)
+    B, H, W = m.shape
+    if tuple(img.shape) != (B, H, W, 3):
+        raise RuntimeError("image must be uint8 [B,H,W,3]")
+    out = torch.empty_like(m)
+    check(_lib.lib().ofx_expand_mask(_ptr(m), _ptr(img), _ptr(out), None, B, H, W, int(edge_thres), int(ksize), _stream()),
+          "ofx_expand_mask")
+    return out
+
+
+def travel_distance(flow: torch.Tensor, conf: torch.Tensor, conf_floor: float = 0.9) -> torch.Tensor:
+    fl = _chk(flow, "flow", torch.float32)
+    c = _chk(conf, "confidence", torch.float32)
+    B, H, W, _ = fl.shape
+    out = torch.empty((B, H, W), dtype=torch.float32, device=fl.device)
+    check(_lib.lib().ofx_travel_distance(_ptr(fl), _ptr(c), _ptr(out), B, H, W, float(conf_floor), _stream()),
+          "ofx_travel_distance")
+    return out
+
+
+def travel_mask(conf, flow, dist, travel, thres: float, warp_mode: str = "cv2_cubic") -> Tuple[torch.Tensor, torch.Tensor]:
+    """confidence_to_mask core (before the 15x15 dilation): returns (raw mask, new travel)."""
+    c = _chk(conf, "confidence", torch.float32)
+    fl = _chk(flow, "flow", torch.float32)
+    d = _chk(dist, "dist", torch.float32)
+    t = _chk(travel, "travel", torch.float32)
+    B, H, W = c.shape
+    tout = torch.empty_like(t)
+    raw = torch.empty((B, H, W), dtype=torch.uint8, device=c.device)
+    check(_lib.lib().ofx_travel_mask(_ptr(c), _ptr(fl), _ptr(d), _ptr(t), _ptr(tout), _ptr(raw), B, H, W, float(thres),
+                                     WARP_MODES[warp_mode], _stream()), "ofx_travel_mask")
+    return raw, tout
+
+
+def merge_images(base, second, mask) -> torch.Tensor:
+    b = _chk(base, "base", torch.uint8)
+    s = _chk(second, "second", torch.uint8)
+    m = _chk(mask, "mask", torch.uint8)
+    B, H, W, Cn = b.shape
+    out = torch.empty_like(b)
+    check(_lib.lib().ofx_merge_images(_ptr(b), _ptr(s), _ptr(m), _ptr(out), B, H, W, Cn, _stream()), "ofx_merge_images")
+    return out
+
+
+def mix_frames(raw, warped, mask, ppw: float) -> torch.Tensor:
+    r = _chk(raw, "raw", torch.uint8)
+    w = _chk(warped, "warped", torch.uint8)
+    m = _chk(mask, "mask", torch.uint8)
+    B, H, W, Cn = r.shape
+    out = torch.empty_like(r)
+    check(_lib.lib().ofx_mix_frames(_ptr(r), _ptr(w), _ptr(m), _ptr(out), B, H, W, Cn, float(ppw), _stream()), "ofx_mix_frames")
+    return out
+
+
+def conf_sum(x: torch.Tensor, chan: int) -> torch.Tensor:
+    """x f32 [N,H,W,nchan] -> f64 [N] sums of channel `chan` over H,W."""
+    t = _chk(x, "x", torch.float32)
+    N, H, W, nc = t.shape
+    out = torch.empty((N,), dtype=torch.float64, device=t.device)
+    check(_lib.lib().ofx_conf_sum(_ptr(t), _ptr(out), N, H * W, nc, int(chan), _stream()), "ofx_conf_sum")
+    return out
+
+
+def fb_confidence(flow_fw: torch.Tensor, flow_bw: torch.Tensor, sigma: float = 3.0) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Extension: forward-backward consistency (confidence, log_confidence), each f32 [B,H,W]."""
+    a = _chk(flow_fw, "flow_fw", torch.float32)
+    b = _chk(flow_bw, "flow_bw", torch.float32)
+    B, H, W, _ = a.shape
+    conf = torch.empty((B, H, W), dtype=torch.float32, device=a.device)
+    logc = torch.empty_like(conf)
+    check(_lib.lib().ofx_fb_confidence(_ptr(a), _ptr(b), _ptr(conf), _ptr(logc), B, H, W, float(sigma), _stream()),
+          "ofx_fb_confidence")
+    return conf, logc
+
+
+def warp_and_mask(frame, flow, conf, warp_mode="bilinear", sign=1.0, thres=0.95, ksize=7, cmp_gt=False):
+    """Fused tail of the hot path for a batch: (warped uint8 [B,H,W,C], mask uint8 [B,H,W])."""
+    fl = _chk(flow, "flow", torch.float32)
+    c = _chk(conf, "confidence", torch.float32)
+    fr = _chk(frame, "frame", torch.uint8)
+    B, H, W, _ = fl.shape
+    shared = fr.dim() == 3
+    Cn = fr.shape[-1]
+    warped = torch.empty((B, H, W, Cn), dtype=torch.uint8, device=fr.device)
+    mask = torch.empty((B, H, W), dtype=torch.uint8, device=fr.device)
+    check(_lib.lib().ofx_warp_and_mask(_ptr(fr), 0 if shared else H * W * Cn, _ptr(fl), _ptr(c), _ptr(warped), _ptr(mask),
+                                       B, H, W, Cn, WARP_MODES[warp_mode], float(sign), float(thres), int(ksize),
+                                       1 if cmp_gt else 0, _stream()), "ofx_warp_and_mask")
+    return warped, mask
+
+
+# --------------------------------------------------------------------------------------
+# network building blocks (exposed for stage-level parity tests and custom pipelines)
+# --------------------------------------------------------------------------------------
+def pack_conv_weight(w_oihw: torch.Tensor, cin_pad: Optional[int] = None) -> torch.Tensor:
+    """OIHW fp32 (CPU) -> packed [Cout, Kpad] fp32 (CPU)."""
+    w = w_oihw.detach().to(torch.float32).contiguous().cpu()
+    co, ci, kh, kw = w.shape
+    cp = cin_pad if cin_pad else ((ci + 3) // 4) * 4
+    L = _lib.lib()
+    kpad = L.ofx_pack_conv_weight(None, co, ci, kh, kw, cp, None)
+    if kpad < 0:
+        raise _lib.OfxError(int(kpad), "ofx_pack_conv_weight")
+    out = torch.empty((co, kpad), dtype=torch.float32)
+    L.ofx_pack_conv_weight(C.c_void_p(w.data_ptr()), co, ci, kh, kw, cp, C.c_void_p(out.data_ptr()))
+    return out
+
+
+def conv2d_nhwc(x: torch.Tensor, w_packed: torch.Tensor, kh: int, kw: int, cout: int, *, stride: int = 1,
+                shift: Optional[torch.Tensor] = None, scale: Optional[torch.Tensor] = None, act: Optional[str] = None,
+                x2: Optional[torch.Tensor] = None, res: Optional[torch.Tensor] = None,
+                nmean: Optional[torch.Tensor] = None, nrstd: Optional[torch.Tensor] = None, tile: int = 0) -> torch.Tensor:
+    """Plain-epilogue convolution: x [B,H,W,C0] (+ optional second channel segment x2 [B,H,W,C1]),
+    'same' padding (k//2).  Returns [B,Hout,Wout,cout]."""
+    x = _chk(x, "x", torch.float32)
+    B, H, W, c0 = x.shape
+    d = ConvDesc()
+    d.in0, d.ld0, d.c0 = x.data_ptr(), c0, c0
+    if x2 is not None:
+        x2 = _chk(x2, "x2", torch.float32)
+        d.in1, d.ld1, d.c1 = x2.data_ptr(), x2.shape[-1], x2.shape[-1]
+    wp = _chk(w_packed, "w_packed", torch.float32)
+    d.w = wp.data_ptr()
+    d.scale = 0 if scale is None else _chk(scale, "scale", torch.float32).data_ptr()
+    d.shift = 0 if shift is None else _chk(shift, "shift", torch.float32).data_ptr()
+    ph, pw = kh // 2, kw // 2
+    Ho, Wo = (H + 2 * ph - kh) // stride + 1, (W + 2 * pw - kw) // stride + 1
+    out = torch.empty((B, Ho, Wo, cout), dtype=torch.float32, device=x.device)
+    d.out, d.ldo = out.data_ptr(), cout
+    if res is not None:
+        res = _chk(res, "res", torch.float32)
+        d.res, d.ldres = res.data_ptr(), res.shape[-1]
+    if nmean is not None:
+        d.nmean = _chk(nmean, "nmean", torch.float32).data_ptr()
+        d.nrstd = _chk(nrstd, "nrstd", torch.float32).data_ptr()
+    d.B, d.Hin, d.Win, d.Hout, d.Wout, d.Cout = B, H, W, Ho, Wo, cout
+    d.KH, d.KW, d.stride, d.padH, d.padW = kh, kw, stride, ph, pw
+    d.act, d.epi, d.tile = ACTS[act], EPI_PLAIN, tile
+    check(_lib.lib().ofx_conv2d(C.byref(d), _stream()), "ofx_conv2d")
+    return out
+
+
+def conv2d_desc(d: ConvDesc) -> None:
+    check(_lib.lib().ofx_conv2d(C.byref(d), _stream()), "ofx_conv2d")
+
+
+def inorm_stats(x: torch.Tensor, eps: float = 1e-5) -> Tuple[torch.Tensor, torch.Tensor]:
+    x = _chk(x, "x", torch.float32)
+    B, H, W, Cn = x.shape
+    mean = torch.empty((B, Cn), dtype=torch.float32, device=x.device)
+    rstd = torch.empty_like(mean)
+    scratch = torch.empty((B * 64 * Cn * 2,), dtype=torch.float64, device=x.device)
+    check(_lib.lib().ofx_inorm_stats(_ptr(x), Cn, _ptr(mean), _ptr(rstd), _ptr(scratch), B, H * W, Cn, float(eps), _stream()),
+          "ofx_inorm_stats")
+    return mean, rstd
+
+
+def inorm_apply(x, mean, rstd, res=None, res_mean=None, res_rstd=None, relu=True) -> torch.Tensor:
+    x = _chk(x, "x", torch.float32)
+    B, H, W, Cn = x.shape
+    out = torch.empty_like(x)
+    check(_lib.lib().ofx_inorm_apply(_ptr(x), _ptr(mean), _ptr(rstd), _ptr(res), _ptr(res_mean), _ptr(res_rstd), _ptr(out),
+                                     B, H * W, Cn, 1 if relu else 0, _stream()), "ofx_inorm_apply")
+    return out
+
+
+def preprocess_u8(img: torch.Tensor, bgr: bool = False) -> torch.Tensor:
+    x = _chk(img, "img", torch.uint8)
+    if x.shape[-1] != 3:
+        raise RuntimeError("img must be [...,3]")
+    out = torch.empty(tuple(x.shape[:-1]) + (4,), dtype=torch.float32, device=x.device)
+    check(_lib.lib().ofx_preprocess_u8(_ptr(x), _ptr(out), x.numel() // 3, 1 if bgr else 0, _stream()), "ofx_preprocess_u8")
+    return out
+
+
+def corr_volume(f1: torch.Tensor, f2: torch.Tensor, levels: int = 4) -> List[torch.Tensor]:
+    """f1, f2 f32 [B,h,w,D] (NHWC) -> pyramid list, level l: [B*h*w, h>>l, w>>l]."""
+    a = _chk(f1, "fmap1", torch.float32)
+    b = _chk(f2, "fmap2", torch.float32)
+    B, h, w, D = a.shape
+    pyr = [torch.empty((B * h * w, h >> l, w >> l), dtype=torch.float32, device=a.device) for l in range(levels)]
+    arr = (C.c_void_p * levels)(*[p.data_ptr() for p in pyr])
+    check(_lib.lib().ofx_corr_volume(_ptr(a), _ptr(b), arr, B, h, w, D, levels, _stream()), "ofx_corr_volume")
+    return pyr
+
+
+def corr_lookup(pyr: Sequence[torch.Tensor], coords: torch.Tensor, B: int, h: int, w: int, radius: int = 4) -> torch.Tensor:
+    """coords f32 [B,h,w,2] (x,y) -> [B,h,w,L*(2r+1)^2] (channels-last version of CorrBlock.__call__)."""
+    c = _chk(coords, "coords", torch.float32)
+    for i, p in enumerate(pyr):
+        _chk(p, f"pyr[{i}]", torch.float32)
+    levels = len(pyr)
+    nch = levels * (2 * radius + 1) ** 2
+    out = torch.empty((B, h, w, nch), dtype=torch.float32, device=c.device)
+    arr = (C.c_void_p * levels)(*[p.data_ptr() for p in pyr])
+    check(_lib.lib().ofx_corr_lookup(arr, _ptr(c), _ptr(out), nch, B, h, w, levels, radius, _stream()), "ofx_corr_lookup")
+    return out
+
+
+def local_corr(fmap1: torch.Tensor, fmap2: torch.Tensor, coords: torch.Tensor, radius: int) -> torch.Tensor:
+    """`alt_cuda_corr.forward` semantics; see alt_cuda_corr.py."""
+    a = _chk(fmap1, "fmap1", torch.float32)
+    b = _chk(fmap2, "fmap2", torch.float32)
+    c = _chk(coords, "coords", torch.float32)
+    B, H1, W1, Cn = a.shape
+    _, H2, W2, _ = b.shape
+    N = c.shape[1]
+    rd = 2 * radius + 1
+    out = torch.empty((B, N, rd * rd, H1, W1), dtype=torch.float32, device=a.device)
+    check(_lib.lib().ofx_local_corr_fwd(_ptr(a), _ptr(b), _ptr(c), _ptr(out), B, H1, W1, H2, W2, Cn, N, radius, _stream()),
+          "ofx_local_corr_fwd")
+    return out
+
+
+def avgpool2_nhwc(x: torch.Tensor) -> torch.Tensor:
+    x = _chk(x, "x", torch.float32)
+    B, H, W, Cn = x.shape
+    out = torch.empty((B, H // 2, W // 2, Cn), dtype=torch.float32, device=x.device)
+    check(_lib.lib().ofx_avgpool2_nhwc(_ptr(x), _ptr(out), B, H, W, Cn, _stream()), "ofx_avgpool2_nhwc")
+    return out
+
+
+def upsample_flow(coords1: torch.Tensor, mask: torch.Tensor) -> torch.Tensor:
+    """coords1 f32 [B,h,w,2], mask f32 [B,h,w,576] -> flow_up f32 [B,8h,8w,2]."""
+    c = _chk(coords1, "coords1", torch.float32)
+    m = _chk(mask, "mask", torch.float32)
+    B, h, w, _ = c.shape
+    out = torch.empty((B, 8 * h, 8 * w, 2), dtype=torch.float32, device=c.device)
+    check(_lib.lib().ofx_upsample_flow(_ptr(c), _ptr(m), _ptr(out), B, h, w, _stream()), "ofx_upsample_flow")
+    return out

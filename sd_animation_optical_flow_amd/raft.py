@@ -1,0 +1,130 @@
+"""Python handle of the native RAFT engine (csrc/raft_engine.cpp).
+
+`RaftEngine(state_dict)` packs and uploads the weights once (state_dict keys are the reference
+checkpoint's, `raft-things.pth` loads unchanged -- `module.` prefixes are accepted);
+`forward(image1, image2)` runs `RAFT.forward(iters=20, test_mode=True)` (RAFT/core/raft.py:86-144)
+for a batch of uint8 frame pairs resident on the GPU and returns flow f32[B,H,W,2] on the GPU.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Optional, Tuple
+
+import torch
+import torch.nn.functional as F
+
+from . import _lib
+from ._lib import check
+
+FLAG_BGR, FLAG_SHARED_IMG2, FLAG_SHARED_IMG1, FLAG_ALT_CORR = 1, 2, 4, 8
+
+
+class RaftEngine:
+    def __init__(self, state_dict: Dict[str, torch.Tensor], device: Optional[torch.device] = None):
+        L = _lib.lib()
+        if not torch.cuda.is_available():
+            raise RuntimeError("RaftEngine needs a HIP device (no CPU fallback)")
+        self.device = torch.device(device if device is not None else "cuda")
+        if self.device.index is not None:
+            torch.cuda.set_device(self.device)
+        keep = []
+        arr = (_lib.Tensor * len(state_dict))()
+        n = 0
+        for k, v in state_dict.items():
+            if not torch.is_tensor(v) or not v.dtype.is_floating_point:
+                continue
+            t = v.detach().to(torch.float32).contiguous().cpu()
+            if t.dim() > 4:
+                continue
+            keep.append(t)
+            arr[n].name = k.encode()
+            arr[n].data = t.data_ptr()
+            arr[n].ndim = t.dim()
+            for j in range(4):
+                arr[n].shape[j] = t.shape[j] if j < t.dim() else 1
+            n += 1
+        h = C.c_void_p()
+        with torch.cuda.device(self.device):
+            check(L.ofx_raft_create(arr, n, C.byref(h)), "ofx_raft_create")
+        self._h = h
+        self._ws: Optional[torch.Tensor] = None
+        self._ws_key: Optional[Tuple[int, int, int]] = None
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            try:
+                _lib.lib().ofx_raft_destroy(h)
+            except Exception:
+                pass
+            self._h = None
+
+    def _workspace(self, B: int, H: int, W: int) -> torch.Tensor:
+        need = _lib.lib().ofx_raft_workspace_bytes(self._h, B, H, W)
+        if need == 0:
+            raise RuntimeError(f"unsupported shape B={B} H={H} W={W} (H, W must be multiples of 8)")
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = None
+            self._ws = torch.empty((need,), dtype=torch.uint8, device=self.device)
+        return self._ws
+
+    @staticmethod
+    def pad_to_8(img: torch.Tensor) -> torch.Tensor:
+        """InputPadder('sintel') of RAFT/core/utils/utils.py:7-19 for uint8 [B,H,W,3] tensors:
+        replicate padding, centred.  No-op when H and W are multiples of 8."""
+        H, W = img.shape[1:3]
+        ph = (((H // 8) + 1) * 8 - H) % 8
+        pw = (((W // 8) + 1) * 8 - W) % 8
+        if ph == 0 and pw == 0:
+            return img
+        x = img.permute(0, 3, 1, 2).float()
+        x = F.pad(x, (pw // 2, pw - pw // 2, ph // 2, ph - ph // 2), mode="replicate")
+        return x.permute(0, 2, 3, 1).to(torch.uint8).contiguous()
+
+    @torch.no_grad()
+    def forward(self, image1: torch.Tensor, image2: torch.Tensor, iters: int = 20, bgr: bool = False,
+                alternate_corr: bool = False, want_low: bool = False):
+        """image1: uint8 [B,H,W,3] or [H,W,3] (shared by the batch); image2 likewise.  Flow is defined
+        on image1's grid and points into image2.  Returns flow_up f32[B,H,W,2] (and flow_low)."""
+        for nm, t in (("image1", image1), ("image2", image2)):
+            if not t.is_cuda:
+                raise RuntimeError(f"{nm} must be a CUDA tensor")
+            if t.dtype != torch.uint8:
+                raise RuntimeError(f"{nm} must be uint8")
+        flags = FLAG_BGR if bgr else 0
+        sh1, sh2 = image1.dim() == 3, image2.dim() == 3
+        if sh1 and sh2:
+            image1, sh1 = image1[None], False
+            image2, sh2 = image2[None], False
+        i1 = self.pad_to_8(image1[None] if sh1 else image1).contiguous()
+        i2 = self.pad_to_8(image2[None] if sh2 else image2).contiguous()
+        B = i2.shape[0] if sh1 else i1.shape[0]
+        H, W = i1.shape[1:3]
+        if tuple(i2.shape[1:]) != (H, W, 3) or i1.shape[3] != 3:
+            raise RuntimeError(f"image shapes differ: {tuple(i1.shape)} vs {tuple(i2.shape)}")
+        if not sh1 and not sh2 and i1.shape[0] != i2.shape[0]:
+            raise RuntimeError("batch sizes differ")
+        if sh1:
+            flags |= FLAG_SHARED_IMG1
+        if sh2:
+            flags |= FLAG_SHARED_IMG2
+        if alternate_corr:
+            flags |= FLAG_ALT_CORR
+        ws = self._workspace(B, H, W)
+        flow_up = torch.empty((B, H, W, 2), dtype=torch.float32, device=self.device)
+        flow_low = torch.empty((B, H // 8, W // 8, 2), dtype=torch.float32, device=self.device) if want_low else None
+        stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        check(_lib.lib().ofx_raft_forward(self._h, C.c_void_p(i1.data_ptr()), C.c_void_p(i2.data_ptr()), B, H, W, int(iters),
+                                          flags, C.c_void_p(flow_up.data_ptr()),
+                                          C.c_void_p(flow_low.data_ptr() if want_low else 0),
+                                          C.c_void_p(ws.data_ptr()), ws.numel(), stream), "ofx_raft_forward")
+        return (flow_up, flow_low) if want_low else flow_up
+
+    def buffer(self, name: str) -> torch.Tensor:
+        """Copy of a named intermediate of the last forward (flat f32) -- for stage-level parity tests."""
+        p, n = C.c_void_p(), C.c_size_t()
+        check(_lib.lib().ofx_raft_buffer(self._h, name.encode(), C.byref(p), C.byref(n)), "ofx_raft_buffer")
+        ws = self._ws
+        off = p.value - ws.data_ptr()
+        assert 0 <= off and off + 4 * n.value <= ws.numel()
+        return ws[off:off + 4 * n.value].view(torch.float32).clone()

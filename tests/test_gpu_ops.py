@@ -1,0 +1,368 @@
+"""-m gpu: operator-level parity of the HIP kernels (through the C ABI) against the CPU oracle.
+
+Tolerances: integer / byte paths are bit-exact; fp32 paths are compared with an absolute tolerance
+stated per test (fp32 accumulation order differs between MFMA tiles and the CPU's loops).
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from oracle import mask_oracle as MO
+from oracle import raft_oracle as RO
+from oracle import warp_oracle as WO
+
+
+def _ops():
+    from sd_animation_optical_flow_amd import ops
+    return ops
+
+
+def nhwc(x):  # NCHW cpu -> NHWC cuda
+    return x.permute(0, 2, 3, 1).contiguous().cuda()
+
+
+def nchw(x):  # NHWC cuda -> NCHW cpu
+    return x.permute(0, 3, 1, 2).contiguous().cpu()
+
+
+# --------------------------------------------------------------------------------------
+# implicit-GEMM convolution
+# --------------------------------------------------------------------------------------
+CONV_CASES = [
+    # (B, H, W, Cin, Cout, kh, kw, stride, act, tile)
+    (2, 24, 20, 64, 64, 3, 3, 1, "relu", 0),
+    (1, 24, 20, 64, 96, 3, 3, 2, None, 0),
+    (2, 17, 13, 128, 126, 3, 3, 1, "relu", 0),       # ragged M and N
+    (1, 16, 16, 324, 256, 1, 1, 1, "relu", 0),       # K = 324 (not a multiple of 32)
+    (1, 12, 20, 384, 128, 1, 5, 1, "tanh", 0),
+    (1, 20, 12, 384, 256, 5, 1, 1, "sigmoid", 0),
+    (1, 16, 16, 256, 2, 3, 3, 1, None, 0),           # tiny Cout
+    (1, 16, 16, 256, 576, 1, 1, 1, None, 0),
+    (3, 40, 24, 64, 64, 1, 1, 2, None, 0),           # 1x1 stride-2 downsample
+    (1, 32, 32, 128, 128, 3, 3, 1, None, 128128),
+    (1, 32, 32, 128, 128, 3, 3, 1, None, 128064),
+    (1, 32, 32, 128, 128, 3, 3, 1, None, 128032),
+    (1, 32, 32, 128, 128, 3, 3, 1, None, 64064),
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv2d_matches_torch(cuda, case):
+    ops = _ops()
+    B, H, W, ci, co, kh, kw, stride, act, tile = case
+    g = torch.Generator().manual_seed(hash(case) % 1000)
+    x = torch.randn((B, ci, H, W), generator=g)
+    w = torch.randn((co, ci, kh, kw), generator=g) / np.sqrt(ci * kh * kw)
+    b = torch.randn((co,), generator=g)
+    ref = F.conv2d(x, w, b, stride=stride, padding=(kh // 2, kw // 2))
+    ref = {"relu": torch.relu, "tanh": torch.tanh, "sigmoid": torch.sigmoid, None: lambda t: t}[act](ref)
+    wp = ops.pack_conv_weight(w).cuda()
+    out = ops.conv2d_nhwc(nhwc(x), wp, kh, kw, co, stride=stride, shift=b.cuda(), act=act, tile=tile)
+    torch.cuda.synchronize()
+    err = (nchw(out) - ref).abs().max().item()
+    assert err < 2e-5, err      # fp32 accumulate, K <= 3456
+
+
+def test_conv2d_two_segments_residual_and_scale(cuda):
+    ops = _ops()
+    g = torch.Generator().manual_seed(3)
+    xa = torch.randn((2, 128, 12, 16), generator=g)
+    xb = torch.randn((2, 256, 12, 16), generator=g)
+    w = torch.randn((128, 384, 3, 3), generator=g) / 60
+    sc = torch.rand((128,), generator=g) + 0.5
+    sh = torch.randn((128,), generator=g)
+    res = torch.randn((2, 128, 12, 16), generator=g)
+    y = F.conv2d(torch.cat([xa, xb], 1), w, None, padding=1) * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)
+    ref = torch.relu(torch.relu(y) + res)
+    out = ops.conv2d_nhwc(nhwc(xa), ops.pack_conv_weight(w).cuda(), 3, 3, 128, shift=sh.cuda(), scale=sc.cuda(), act="relu",
+                          x2=nhwc(xb), res=nhwc(res))
+    assert (nchw(out) - ref).abs().max().item() < 2e-5
+
+
+def test_conv2d_padded_cin_and_fused_instance_norm(cuda):
+    ops = _ops()
+    g = torch.Generator().manual_seed(4)
+    # 7x7 stride-2 conv on a 3-channel image padded to 4 channels
+    img = torch.randint(0, 256, (2, 40, 48, 3), generator=g, dtype=torch.uint8)
+    x0 = ops.preprocess_u8(img.cuda())
+    xr = (2 * (img.float() / 255.0) - 1.0)
+    assert torch.equal(x0[..., :3].cpu(), xr) and float(x0[..., 3].abs().max()) == 0.0
+    xbgr = ops.preprocess_u8(img.cuda(), bgr=True)
+    assert torch.equal(xbgr[..., :3].cpu(), xr.flip(-1))
+    w = torch.randn((64, 3, 7, 7), generator=g) / 12
+    b = torch.randn((64,), generator=g)
+    ref = F.conv2d(xr.permute(0, 3, 1, 2), w, b, stride=2, padding=3)
+    raw = ops.conv2d_nhwc(x0, ops.pack_conv_weight(w, 4).cuda(), 7, 7, 64, stride=2, shift=b.cuda())
+    assert (nchw(raw) - ref).abs().max().item() < 2e-5
+    # instance-norm statistics + apply
+    mean, rstd = ops.inorm_stats(raw)
+    mref = ref.mean((2, 3))
+    vref = ref.var((2, 3), unbiased=False)
+    assert (mean.cpu() - mref).abs().max().item() < 1e-5
+    assert (rstd.cpu() - 1 / torch.sqrt(vref + 1e-5)).abs().max().item() < 1e-4
+    y = ops.inorm_apply(raw, mean, rstd, relu=True)
+    yref = torch.relu(F.instance_norm(ref))
+    assert (nchw(y) - yref).abs().max().item() < 2e-5
+    # norm + relu fused into the next conv's operand load == conv of the materialised tensor
+    w2 = torch.randn((64, 64, 3, 3), generator=g) / 24
+    ref2 = F.conv2d(yref, w2, None, padding=1)
+    out2 = ops.conv2d_nhwc(raw, ops.pack_conv_weight(w2).cuda(), 3, 3, 64, nmean=mean, nrstd=rstd)
+    assert (nchw(out2) - ref2).abs().max().item() < 5e-5
+    # residual merge with a normalised shortcut
+    r = torch.randn(ref.shape, generator=g)
+    rm, rs = ops.inorm_stats(nhwc(r))
+    z = ops.inorm_apply(raw, mean, rstd, res=nhwc(r), res_mean=rm, res_rstd=rs)
+    zref = torch.relu(F.instance_norm(r) + yref)
+    assert (nchw(z) - zref).abs().max().item() < 2e-5
+
+
+# --------------------------------------------------------------------------------------
+# correlation
+# --------------------------------------------------------------------------------------
+@pytest.mark.parametrize("shape", [(2, 20, 16), (1, 24, 32), (1, 17, 19)])
+def test_corr_volume_pyramid_and_lookup(cuda, shape):
+    ops = _ops()
+    B, h, w = shape
+    g = torch.Generator().manual_seed(5)
+    f1 = torch.randn((B, 256, h, w), generator=g)
+    f2 = torch.randn((B, 256, h, w), generator=g)
+    ref_pyr = RO.corr_pyramid(f1, f2)
+    pyr = ops.corr_volume(nhwc(f1), nhwc(f2))
+    for l in range(4):
+        err = (pyr[l].cpu() - ref_pyr[l][:, 0]).abs().max().item()
+        assert err < 3e-5, (l, err)
+    # lookups: integer, fractional and far out-of-range coordinates
+    coords = RO.coords_grid(B, h, w)
+    for amp in (0.0, 3.3, 40.0):
+        c = coords + (torch.rand((B, 2, h, w), generator=g) - 0.5) * 2 * amp
+        ref = RO.corr_lookup(ref_pyr, c)
+        out = ops.corr_lookup(pyr, nhwc(c), B, h, w)
+        err = (nchw(out) - ref).abs().max().item()
+        assert err < 1e-4, (amp, err)
+
+
+def test_local_corr_matches_alt_cuda_corr_semantics(cuda):
+    ops = _ops()
+    g = torch.Generator().manual_seed(6)
+    B, h, w, C = 2, 12, 10, 64
+    f1 = torch.randn((B, h, w, C), generator=g)
+    f2 = torch.randn((B, h // 2, w // 2, C), generator=g)
+    coords = torch.stack(torch.meshgrid(torch.arange(w).float(), torch.arange(h).float(), indexing="xy"), -1)
+    coords = (coords[None, None] / 2 + (torch.rand((B, 1, h, w, 2), generator=g) - 0.5) * 9).contiguous()
+    ref = RO.local_corr_level(f1, f2, coords, 4)
+    out = ops.local_corr(f1.cuda(), f2.cuda(), coords.cuda(), 4)
+    assert tuple(out.shape) == (B, 1, 81, h, w)
+    assert (out.cpu() - ref).abs().max().item() < 1e-4
+    # property: the volume-free path equals the CorrBlock path
+    fa = torch.randn((1, 256, 16, 16), generator=g)
+    fb = torch.randn((1, 256, 16, 16), generator=g)
+    c = RO.coords_grid(1, 16, 16) + (torch.rand((1, 2, 16, 16), generator=g) - 0.5) * 6
+    want = RO.corr_lookup(RO.corr_pyramid(fa, fb), c)[:, :81]
+    got = ops.local_corr(nhwc(fa), nhwc(fb), nhwc(c)[:, None].contiguous(), 4)[:, 0] / 16.0
+    assert (got.cpu() - want).abs().max().item() < 1e-4
+    p = ops.avgpool2_nhwc(nhwc(fb))
+    assert (nchw(p) - F.avg_pool2d(fb, 2, 2)).abs().max().item() < 1e-6
+
+
+def test_local_corr_preconditions_raise(cuda):
+    ops = _ops()
+    f = torch.zeros((1, 8, 8, 32))
+    c = torch.zeros((1, 1, 8, 8, 2))
+    with pytest.raises(RuntimeError, match="CUDA"):
+        ops.local_corr(f, f.cuda(), c.cuda(), 4)            # correlation.cpp:19
+    with pytest.raises(RuntimeError, match="contiguous"):
+        ops.local_corr(f.cuda().transpose(1, 2), f.cuda(), c.cuda(), 4)   # correlation.cpp:20
+
+
+def test_upsample_flow(cuda):
+    ops = _ops()
+    g = torch.Generator().manual_seed(7)
+    B, h, w = 2, 9, 11
+    flow = torch.randn((B, 2, h, w), generator=g) * 3
+    mask = torch.randn((B, 576, h, w), generator=g) * 2
+    ref = RO.upsample_flow(flow, mask)
+    coords1 = RO.coords_grid(B, h, w) + flow
+    out = ops.upsample_flow(nhwc(coords1), nhwc(mask))
+    # coords1 - grid re-derives flow with one extra rounding: tolerance 8 * 2^-18
+    assert (nchw(out) - ref).abs().max().item() < 1e-4
+
+
+# --------------------------------------------------------------------------------------
+# warp
+# --------------------------------------------------------------------------------------
+def _warp_inputs(seed, H=45, W=37, C=3, amp=9.0):
+    rng = np.random.default_rng(seed)
+    frame = rng.integers(0, 256, (H, W, C), dtype=np.uint8)
+    flow = (rng.standard_normal((H, W, 2)) * amp).astype(np.float32)
+    flow[0, 0] = (1000.0, -1000.0)          # far outside
+    flow[1, 1] = (0.0, 0.0)
+    flow[2, 2] = (0.5, 0.5)                 # exact tie for the bilinear uint8 rounding
+    flow[3, 3] = (-3.0, -3.0)               # samples the border
+    return frame, flow
+
+
+@pytest.mark.parametrize("sign,conv", [(1.0, "pdcnet"), (-1.0, "raft")])
+def test_warp_cv2_cubic_u8_bit_exact(cuda, sign, conv):
+    ops = _ops()
+    frame, flow = _warp_inputs(11)
+    ref = WO.warp_frame(frame, flow, mode="cv2_cubic", convention=conv)
+    out = ops.warp(torch.from_numpy(frame).cuda(), torch.from_numpy(flow).cuda(), mode="cv2_cubic", sign=sign)
+    assert np.array_equal(out.cpu().numpy(), ref)
+
+
+def test_warp_cv2_cubic_f32_bit_exact(cuda):
+    ops = _ops()
+    frame, flow = _warp_inputs(12, C=1)
+    f32 = (frame.astype(np.float32) * 0.37 - 20).astype(np.float32)
+    ref = WO.warp_frame(f32, flow, mode="cv2_cubic")
+    out = ops.warp(torch.from_numpy(f32).cuda(), torch.from_numpy(flow).cuda(), mode="cv2_cubic")
+    assert np.array_equal(out.cpu().numpy(), ref)
+
+
+@pytest.mark.parametrize("mode", ["bilinear", "bicubic"])
+def test_warp_float_modes_against_oracle_and_grid_sample(cuda, mode):
+    ops = _ops()
+    frame, flow = _warp_inputs(13, C=4)
+    f32 = frame.astype(np.float32)
+    ref = WO.warp_frame(f32, flow, mode=mode)
+    out = ops.warp(torch.from_numpy(f32).cuda(), torch.from_numpy(flow).cuda(), mode=mode).cpu().numpy()
+    assert np.abs(out - ref).max() < 1e-3                 # values up to 255: ~4e-6 relative
+    # independent pin: torch grid_sample with align_corners=True on the same sample positions
+    H, W = flow.shape[:2]
+    mx, my = WO._maps(flow)
+    grid = torch.from_numpy(np.stack([2 * mx / (W - 1) - 1, 2 * my / (H - 1) - 1], -1))[None]
+    gs = F.grid_sample(torch.from_numpy(f32).permute(2, 0, 1)[None], grid, mode=mode, padding_mode="zeros", align_corners=True)
+    gs = gs[0].permute(1, 2, 0).numpy()
+    sane = (np.abs(flow) < 100).all(-1)
+    assert np.abs(out - gs)[sane].max() < 5e-3
+    # uint8: round-half-even of the float result, at most 1 LSB from the oracle on rounding ties
+    ref8 = WO.warp_frame(frame, flow, mode=mode)
+    out8 = ops.warp(torch.from_numpy(frame).cuda(), torch.from_numpy(flow).cuda(), mode=mode).cpu().numpy()
+    d = np.abs(out8.astype(int) - ref8.astype(int))
+    assert d.max() <= 1 and (d > 0).mean() < 1e-3
+
+
+def test_warp_batched_shared_keyframe(cuda):
+    ops = _ops()
+    frame, flow = _warp_inputs(14)
+    flows = np.stack([flow, -flow, flow * 0.25]).astype(np.float32)
+    out = ops.warp(torch.from_numpy(frame).cuda(), torch.from_numpy(flows).cuda(), mode="cv2_cubic").cpu().numpy()
+    for i in range(3):
+        assert np.array_equal(out[i], WO.warp_frame(frame, flows[i], mode="cv2_cubic"))
+
+
+def test_resize_cubic_and_latent_warp(cuda):
+    ops = _ops()
+    rng = np.random.default_rng(15)
+    lat = rng.standard_normal((1, 4, 12, 8)).astype(np.float32)
+    flow = (rng.standard_normal((96, 64, 2)) * 4).astype(np.float32)
+    ref = WO.warp_frame_latent(lat, flow, mode="cv2_cubic")
+    x = torch.from_numpy(lat).permute(0, 2, 3, 1).contiguous().cuda()
+    up = ops.resize_cubic(x, 96, 64)
+    assert np.abs(up[0].cpu().numpy() - WO.resize_cubic(np.transpose(lat[0], (1, 2, 0)), 96, 64)).max() < 1e-5
+    wp = ops.warp(up, torch.from_numpy(flow)[None].cuda(), mode="cv2_cubic")
+    dn = ops.resize_cubic(wp, 12, 8)
+    assert np.abs(dn.permute(0, 3, 1, 2).cpu().numpy() - ref).max() < 1e-4
+
+
+# --------------------------------------------------------------------------------------
+# masks (bit-exact)
+# --------------------------------------------------------------------------------------
+def _conf(seed, H=70, W=53):
+    rng = np.random.default_rng(seed)
+    c = rng.random((H, W)).astype(np.float32)
+    c[::7, ::5] = np.float32(0.95)      # planted exact-threshold values: '<' vs '>' conventions differ here
+    c[3::11, 2::9] = np.float32(0.9)
+    return c
+
+
+@pytest.mark.parametrize("thres,ksize", [(0.95, 7), (0.8, 7), (0.9, 15), (0.5, 1), (0.05, 3)])
+def test_generate_mask_bit_exact(cuda, thres, ksize):
+    ops = _ops()
+    conf = _conf(21)
+    logc = np.log(conf + 1e-3).astype(np.float32)
+    ref_mask, ref_lc = MO.generate_mask(conf, logc, thres, ksize)
+    lc = torch.from_numpy(logc.copy())[None].cuda()
+    out = ops.generate_mask(torch.from_numpy(conf)[None].cuda(), lc, thres, ksize)
+    assert np.array_equal(out[0].cpu().numpy(), ref_mask)
+    assert np.array_equal(lc[0].cpu().numpy(), ref_lc)        # in-place reset, like the reference
+    # keyframe-path convention: inpaint where NOT(conf > thres)
+    ref2 = MO.dilate(np.where(conf > np.float32(thres), 0, 255).astype(np.uint8), MO.ellipse_kernel(ksize))
+    out2 = ops.generate_mask(torch.from_numpy(conf)[None].cuda(), None, thres, ksize, cmp_gt=True)
+    assert np.array_equal(out2[0].cpu().numpy(), ref2)
+
+
+def test_generate_mask_edge_shapes(cuda):
+    ops = _ops()
+    for H, W in ((1, 1), (1, 200), (130, 3), (16, 64), (17, 65)):
+        conf = _conf(22, H, W)
+        ref, _ = MO.generate_mask(conf, conf.copy(), 0.95, 7)
+        out = ops.generate_mask(torch.from_numpy(conf)[None].cuda(), None, 0.95, 7)
+        assert np.array_equal(out[0].cpu().numpy(), ref), (H, W)
+
+
+def test_dilate_expand_merge_mix_travel(cuda):
+    ops = _ops()
+    rng = np.random.default_rng(23)
+    H, W = 66, 50
+    m = (rng.random((H, W)) > 0.97).astype(np.uint8) * rng.integers(1, 256, (H, W)).astype(np.uint8)
+    for k in (3, 7, 15):
+        assert np.array_equal(ops.dilate(torch.from_numpy(m)[None].cuda(), k)[0].cpu().numpy(), MO.dilate(m, MO.ellipse_kernel(k)))
+    img = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+    img[10:30, 10:30] = 200             # flat region: no edges
+    mask = (rng.random((H, W)) > 0.9).astype(np.uint8) * 255
+    ref = MO.expand_mask(mask, img)
+    out = ops.expand_mask(torch.from_numpy(mask)[None].cuda(), torch.from_numpy(img)[None].cuda())
+    assert np.array_equal(out[0].cpu().numpy(), ref)
+    # merge / mix
+    a = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+    b = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+    mk = rng.choice(np.array([0, 127, 128, 254, 255], dtype=np.uint8), (H, W))
+    t = lambda x: torch.from_numpy(x)[None].cuda()
+    assert np.array_equal(ops.merge_images(t(a), t(b), t(mk))[0].cpu().numpy(), MO.merge_images(a, b, mk))
+    for ppw in (1.0, 0.3, 0.5):
+        assert np.array_equal(ops.mix_frames(t(a), t(b), t(mk), ppw)[0].cpu().numpy(), MO.mix_propagated_ai_frame(a, b, mk, ppw))
+    # of_calc distance map
+    flow = (rng.standard_normal((H, W, 2)) * 5).astype(np.float32)
+    conf = _conf(24, H, W)
+    ref_v = MO.travel_distance(flow, conf)
+    out_v = ops.travel_distance(t(flow), t(conf))[0].cpu().numpy()
+    assert np.array_equal(out_v, ref_v)
+    # stateful travel-distance mask (confidence_to_mask)
+    travel = (rng.random((H, W)) * 30).astype(np.float32)
+    ref_mask, ref_travel = MO.confidence_to_mask(conf, flow, ref_v, travel, 25.0, "cv2_cubic")
+    raw, new_travel = ops.travel_mask(t(conf), t(flow), t(ref_v), t(travel), 25.0, "cv2_cubic")
+    assert np.array_equal(new_travel[0].cpu().numpy(), ref_travel)
+    assert np.array_equal(ops.dilate(raw, 15)[0].cpu().numpy(), ref_mask)
+    # keyframe score reduction
+    fm = rng.random((5, H, W, 3)).astype(np.float32)
+    s = ops.conf_sum(torch.from_numpy(fm).cuda(), 2).cpu().numpy()
+    assert np.allclose(s, fm[..., 2].astype(np.float64).sum((1, 2)), rtol=1e-12)
+
+
+def test_warp_and_mask_full_size_properties(cuda):
+    """BASELINE size (512x768): size-independent properties instead of a slow CPU comparison."""
+    ops = _ops()
+    H, W = 768, 512
+    g = torch.Generator(device="cpu").manual_seed(31)
+    frame = torch.randint(0, 256, (H, W, 3), generator=g, dtype=torch.uint8).cuda()
+    zero = torch.zeros((2, H, W, 2), device="cuda")
+    conf = torch.rand((2, H, W), generator=g).cuda()
+    for mode in ("bilinear", "bicubic", "cv2_cubic"):
+        warped, mask = ops.warp_and_mask(frame, zero, conf, warp_mode=mode, thres=0.95, ksize=7)
+        assert torch.equal(warped[0], frame) and torch.equal(warped[1], frame)      # identity flow
+    # integer translation == shifted copy with zero fill
+    shift = torch.zeros((1, H, W, 2), device="cuda")
+    shift[..., 0] = 5.0
+    shift[..., 1] = -3.0
+    w2 = ops.warp(frame, shift, mode="cv2_cubic")[0]
+    assert torch.equal(w2[3:, :W - 5], frame[:H - 3, 5:]) and int(w2[:3].max()) == 0 and int(w2[:, W - 5:].max()) == 0
+    # dilation is extensive, idempotent w.r.t. thresholds: mask(thres a) <= mask(thres b) for a <= b
+    m1 = ops.generate_mask(conf, None, 0.5, 7)
+    m2 = ops.generate_mask(conf, None, 0.6, 7)
+    raw = (conf < 0.5).to(torch.uint8) * 255
+    assert bool((m1 >= raw).all()) and bool((m2 >= m1).all())
+    assert set(torch.unique(m1).tolist()) <= {0, 255}
