@@ -1,0 +1,27 @@
+"""Drop-in for the reference's `alt_cuda_corr` torch extension (RAFT/alt_cuda_corr/correlation.cpp:51-54).
+
+    import sd_animation_optical_flow_amd.alt_cuda_corr as alt_cuda_corr
+    corr, = alt_cuda_corr.forward(fmap1, fmap2, coords, radius)      # RAFT/core/corr.py:86
+
+`forward(fmap1 f32[B,H1,W1,C], fmap2 f32[B,H2,W2,C], coords f32[B,N,H1,W1,2], radius) -> [corr]`
+with `corr f32[B,N,(2r+1)^2,H1,W1]`; all tensors must be CUDA and contiguous (RuntimeError otherwise,
+correlation.cpp:19-21).  Unlike the reference, the launch goes to the *current* torch stream (the CUDA
+original uses the legacy default stream) and C only needs to be a multiple of 4 (the original silently
+requires a multiple of 32).  `backward` is training-only (never reached by the reference's no_grad
+callers) and is not provided.
+"""
+from __future__ import annotations
+
+from typing import List
+
+import torch
+
+from . import ops
+
+
+def forward(fmap1: torch.Tensor, fmap2: torch.Tensor, coords: torch.Tensor, radius: int) -> List[torch.Tensor]:
+    return [ops.local_corr(fmap1, fmap2, coords, int(radius))]
+
+
+def backward(*args, **kwargs):
+    raise NotImplementedError("alt_cuda_corr.backward is training-only; the inference hot path never calls it")

@@ -17,6 +17,11 @@
 #include <mutex>
 #include <vector>
 
+// Bit-exact paths (cv2 float cubic, distance map, frame mix) need every multiply and add rounded
+// separately, like the numpy/OpenCV reference: HIP's __fmul_rn/__fadd_rn are plain operators that the
+// default -ffp-contract=fast would fuse into FMAs.  These kernels are HBM-bound; no cost.
+#pragma clang fp contract(off)
+
 namespace {
 
 // ------------------------------------------------------------------------------------------
@@ -480,7 +485,10 @@ __global__ __launch_bounds__(256) void travel_distance_kernel(const float* __res
         // (X + disp).astype(f32) - arange: the f64->f32->subtract round trip of of_calc
         const float mx = (float)((double)map_coord(x, f.x, 1.f) - (double)x);
         const float my = (float)((double)map_coord(y, f.y, 1.f) - (double)y);
-        float v = __fsqrt_rn(__fadd_rn(__fmul_rn(mx, mx), __fmul_rn(my, my)));
+// f32 sqrt on this toolchain is 1-ulp approximate (measured: 83 % exact); the f64 sqrt rounded to f32
+        // is the correctly rounded f32 result (53 >= 2*24+2 bits), matching np.sqrt bit for bit.
+        // Contraction is off for this file, so the sum is mul, mul, add like numpy.
+        float v = (float)sqrt((double)(mx * mx + my * my));
         if (conf[idx] < floor_) v = 0.f;
         out[idx] = v;
     }

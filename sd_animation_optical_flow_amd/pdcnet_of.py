@@ -1,0 +1,129 @@
+"""Drop-in for the reference's `pdcnet_of.py` call surface (pdcnet_of.py:19-79), MI355X-native.
+
+Exports exactly the names the reference's drivers import
+(`ofgen_pixel_inpaint.py:17`, `ofgen_keyframe_inpaint.py:26`):
+
+    create_of_algo(ckpt) -> algo
+    algo.calc(frame1_bgr, frame2_bgr) -> (flow f32[H,W,2], confidence f32[H,W], log_confidence f32[H,W])  numpy
+    algo.calc_batch(src_rgb_u8[B,H,W,3], tgt_rgb_u8[B,H,W,3]) -> (flow_est[B,H,W,2], confidence[B,H,W])   indexable
+    algo.to(device) -> algo
+    warp_frame(frame, flow) -> ndarray          (backward warp: out(y,x) = frame(y+fy, x+fx))
+    warp_frame_latent(latent, flow) -> CPU tensor [1,C,lh,lw]
+
+Differences from the reference, all forced by what is (not) in its tree:
+  * The reference wraps PDCNet+ from the un-vendored DenseMatching checkout (pdcnet_of.py:6-13).  That
+    network is not available, so the flow network here is the RAFT that IS vendored (RAFT/core), run in
+    the same orientation PDCNetPlus.calc uses: flow is defined on frame2 (target) and points into
+    frame1 (source), i.e. RAFT(image1=frame2, image2=frame1).
+  * RAFT emits no confidence; `confidence` / `log_confidence` come from a forward-backward
+    consistency check (ofx_fb_confidence) -- a labelled extension with PDCNetPlus.calc's output shape.
+  * device-resident fast paths are added (`calc_batch_device`, `synthesize`) so flow, warp and mask
+    never leave HBM; the numpy-returning methods keep the reference's host-side contract.
+"""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import numpy as np
+import torch
+
+from . import ops
+from .raft import RaftEngine
+from .weights import load_checkpoint
+
+DEFAULT_WARP_MODE = "cv2_cubic"      # the reference warps with cv2.remap(INTER_CUBIC), pdcnet_of.py:41
+
+
+class PDCNetPlus:
+    """Flow + confidence estimator with the duck type of the reference's `PDCNetPlus` (pdcnet_of.py:45-75)."""
+
+    def __init__(self, ckpt_path="pre_trained_models/PDCNet_plus_m.pth.tar", device=None, iters: int = 20,
+                 confidence_sigma: float = 3.0):
+        self.state_dict = load_checkpoint(ckpt_path)
+        self.iters = int(iters)
+        self.sigma = float(confidence_sigma)
+        self.device = torch.device(device) if device is not None else torch.device("cuda")
+        self.network = RaftEngine(self.state_dict, self.device)   # like `.cuda()` at pdcnet_of.py:61
+
+    def to(self, device):
+        """`pdcnet_model.to(device)` (ofgen_keyframe_inpaint.py:555).  Moving re-uploads the weights."""
+        device = torch.device(device)
+        if device.type != "cuda":
+            raise RuntimeError("this flow algorithm only runs on a HIP device (no CPU fallback)")
+        cur = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        new = device.index if device.index is not None else torch.cuda.current_device()
+        if cur != new:
+            self.device = device
+            self.network = RaftEngine(self.state_dict, device)
+        return self
+
+    # ---- device-resident core ------------------------------------------------------------------
+    @torch.no_grad()
+    def calc_batch_device(self, source: torch.Tensor, target: torch.Tensor, bgr: bool = False,
+                          want_confidence: bool = True):
+        """source/target: uint8 [B,H,W,3] on the device (`source` may be a single [H,W,3] key frame shared
+        by the batch).  Returns (flow f32[B,H,W,2] on the target grid pointing into source, confidence
+        f32[B,H,W], log_confidence f32[B,H,W]) -- all on the device."""
+        net = self.network
+        flow_t = net.forward(target, source, iters=self.iters, bgr=bgr)          # target -> source
+        if not want_confidence:
+            return flow_t, None, None
+        flow_s = net.forward(source, target, iters=self.iters, bgr=bgr)          # source -> target
+        conf, logc = ops.fb_confidence(flow_t, flow_s, self.sigma)
+        return flow_t, conf, logc
+
+    # ---- reference-compatible host API ---------------------------------------------------------
+    @torch.no_grad()
+    def calc(self, frame1: np.ndarray, frame2: np.ndarray):
+        """pdcnet_of.py:65-75: BGR uint8 numpy frames in, numpy (flow, confidence, log_confidence) out."""
+        src = torch.from_numpy(np.ascontiguousarray(frame1)).to(self.device)[None]
+        tgt = torch.from_numpy(np.ascontiguousarray(frame2)).to(self.device)[None]
+        flow, conf, logc = self.calc_batch_device(src, tgt, bgr=True)
+        return flow[0].cpu().numpy(), conf[0].cpu().numpy(), logc[0].cpu().numpy()
+
+    @torch.no_grad()
+    def calc_batch(self, source: torch.Tensor, target: torch.Tensor):
+        """`calc_batch` as called at ofgen_keyframe_inpaint.py:594: RGB uint8 tensors [B,H,W,3] on the
+        device; returns (flow_est, confidence) whose items assign into numpy slots (:598-599)."""
+        flow, conf, _ = self.calc_batch_device(source.contiguous(), target.contiguous(), bgr=False)
+        return flow.cpu(), conf.cpu()
+
+
+def create_of_algo(ckpt) -> PDCNetPlus:
+    """pdcnet_of.py:77-79."""
+    return PDCNetPlus(ckpt)
+
+
+# --------------------------------------------------------------------------------------------------
+def _to_dev(a, device) -> torch.Tensor:
+    t = a if torch.is_tensor(a) else torch.from_numpy(np.ascontiguousarray(a))
+    return t.to(device).contiguous()
+
+
+def warp_frame(frame, flow, mode: Optional[str] = None, device="cuda"):
+    """pdcnet_of.py:34-42.  frame: ndarray [H,W] or [H,W,C], uint8 or float32; flow f32[H,W,2].
+    Returns an ndarray of the same shape/dtype.  `mode`: 'cv2_cubic' (reference-faithful default),
+    'bicubic' (float Keys cubic) or 'bilinear'."""
+    mode = mode or DEFAULT_WARP_MODE
+    fr = np.asarray(frame)
+    squeeze = fr.ndim == 2
+    if fr.dtype not in (np.uint8, np.float32):
+        fr = fr.astype(np.float32)
+    f = _to_dev(fr[:, :, None] if squeeze else fr, device)
+    out = ops.warp(f, _to_dev(np.asarray(flow, dtype=np.float32), device), mode=mode, sign=1.0)
+    out = out.cpu().numpy()
+    return out[:, :, 0] if squeeze else out
+
+
+def warp_frame_latent(latent: torch.Tensor, flow, mode: Optional[str] = None, device="cuda") -> torch.Tensor:
+    """pdcnet_of.py:19-32: cubic-resize the latent to the flow's size, warp, resize back."""
+    mode = mode or DEFAULT_WARP_MODE
+    lat = latent.detach().to(torch.float32).to(device)
+    _, _, lh, lw = lat.shape
+    fl = _to_dev(np.asarray(flow, dtype=np.float32) if not torch.is_tensor(flow) else flow, device)
+    h, w = fl.shape[:2]
+    x = lat.permute(0, 2, 3, 1).contiguous()
+    up = ops.resize_cubic(x, h, w)
+    wp = ops.warp(up, fl[None].contiguous(), mode=mode, sign=1.0)
+    dn = ops.resize_cubic(wp, lh, lw)
+    return dn.permute(0, 3, 1, 2).contiguous().cpu()

@@ -15,6 +15,18 @@ from oracle import raft_oracle as RO
 from oracle import warp_oracle as WO
 
 
+def _diff(a, b):
+    """'' when equal, else a short description (keeps pytest output readable)."""
+    a, b = np.asarray(a), np.asarray(b)
+    if a.shape != b.shape:
+        return f"shape {a.shape} vs {b.shape}"
+    bad = a != b
+    if not bad.any():
+        return ""
+    i = tuple(np.argwhere(bad)[0])
+    return f"{int(bad.sum())}/{a.size} differ; first at {i}: {a[i]!r} vs {b[i]!r}"
+
+
 def _ops():
     from sd_animation_optical_flow_amd import ops
     return ops
@@ -53,7 +65,7 @@ CONV_CASES = [
 def test_conv2d_matches_torch(cuda, case):
     ops = _ops()
     B, H, W, ci, co, kh, kw, stride, act, tile = case
-    g = torch.Generator().manual_seed(hash(case) % 1000)
+    g = torch.Generator().manual_seed(sum(v for v in case if isinstance(v, int)))
     x = torch.randn((B, ci, H, W), generator=g)
     w = torch.randn((co, ci, kh, kw), generator=g) / np.sqrt(ci * kh * kw)
     b = torch.randn((co,), generator=g)
@@ -219,7 +231,7 @@ def test_warp_cv2_cubic_f32_bit_exact(cuda):
     f32 = (frame.astype(np.float32) * 0.37 - 20).astype(np.float32)
     ref = WO.warp_frame(f32, flow, mode="cv2_cubic")
     out = ops.warp(torch.from_numpy(f32).cuda(), torch.from_numpy(flow).cuda(), mode="cv2_cubic")
-    assert np.array_equal(out.cpu().numpy(), ref)
+    assert not _diff(out.cpu().numpy(), ref), _diff(out.cpu().numpy(), ref)
 
 
 @pytest.mark.parametrize("mode", ["bilinear", "bicubic"])
@@ -324,7 +336,8 @@ def test_dilate_expand_merge_mix_travel(cuda):
     t = lambda x: torch.from_numpy(x)[None].cuda()
     assert np.array_equal(ops.merge_images(t(a), t(b), t(mk))[0].cpu().numpy(), MO.merge_images(a, b, mk))
     for ppw in (1.0, 0.3, 0.5):
-        assert np.array_equal(ops.mix_frames(t(a), t(b), t(mk), ppw)[0].cpu().numpy(), MO.mix_propagated_ai_frame(a, b, mk, ppw))
+        d = _diff(ops.mix_frames(t(a), t(b), t(mk), ppw)[0].cpu().numpy(), MO.mix_propagated_ai_frame(a, b, mk, ppw))
+        assert not d, (ppw, d)
     # of_calc distance map
     flow = (rng.standard_normal((H, W, 2)) * 5).astype(np.float32)
     conf = _conf(24, H, W)

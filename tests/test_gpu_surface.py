@@ -1,0 +1,181 @@
+"""-m gpu: the reference's Python call surface (pdcnet_of.py / ofgen_*.py names) on top of the HIP path,
+checked against the oracle's restatement of the same reference functions."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import mask_oracle as MO
+from oracle import raft_oracle as RO
+from oracle import warp_oracle as WO
+
+
+def _pair(seed, H=96, W=128):
+    g = torch.Generator().manual_seed(seed)
+    base = torch.nn.functional.avg_pool2d(torch.rand((1, 3, H + 16, W + 16), generator=g), 5, 1, 2)
+    base = ((base - base.min()) / (base.max() - base.min()) * 255).round().to(torch.uint8)
+    a = base[0, :, 8:8 + H, 8:8 + W].permute(1, 2, 0).contiguous().numpy()
+    b = base[0, :, 10:10 + H, 5:5 + W].permute(1, 2, 0).contiguous().numpy()
+    return a, b          # "BGR" uint8 frames
+
+
+@pytest.fixture(scope="module")
+def algo(cuda, raft_sd):
+    from sd_animation_optical_flow_amd import pdcnet_of
+    return pdcnet_of.create_of_algo(raft_sd)
+
+
+def test_calc_contract_and_flow_orientation(algo, raft_sd):
+    f1, f2 = _pair(1)
+    flow, conf, logc = algo.calc(f1, f2)
+    H, W = f1.shape[:2]
+    assert flow.shape == (H, W, 2) and flow.dtype == np.float32
+    assert conf.shape == (H, W) and logc.shape == (H, W) and conf.dtype == np.float32
+    assert conf.min() >= 0 and conf.max() <= 1 and logc.max() <= 0
+    assert np.allclose(np.exp(logc), conf, atol=1e-6)
+    # flow lives on frame2's grid and points into frame1 == RAFT(image1=frame2, image2=frame1) on RGB
+    ref = RO.raft2_calc(raft_sd, f2, f1)
+    assert np.sqrt(((flow - ref) ** 2).sum(-1)).mean() < 1e-3
+    # forward-backward confidence (extension) against a numpy restatement built from oracle flows
+    bw = RO.raft2_calc(raft_sd, f1, f2)
+    samp = WO.warp_frame(bw, ref, mode="bilinear")
+    e = ref + samp
+    want = np.exp(-(e ** 2).sum(-1) / (2 * 3.0 ** 2))
+    assert np.abs(conf - want).max() < 5e-3
+
+
+def test_calc_batch_contract(algo):
+    f1, f2 = _pair(2)
+    src = torch.from_numpy(np.stack([f1[:, :, ::-1], f2[:, :, ::-1]]).copy()).cuda()      # RGB tensors on the device
+    tgt = torch.from_numpy(np.stack([f2[:, :, ::-1], f1[:, :, ::-1]]).copy()).cuda()
+    flow_est, confidence = algo.calc_batch(src, tgt)
+    ret = np.zeros((2, 1, *f1.shape[:2], 3), np.float32)
+    for i in range(2):                                   # exactly how PDCNetAux consumes it (:598-599)
+        ret[i, 0, :, :, 0:2] = flow_est[i]
+        ret[i, 0, :, :, 2] = confidence[i]
+    flow, conf, _ = algo.calc(f1, f2)
+    assert np.abs(ret[0, 0, :, :, 0:2] - flow).max() < 1e-4 and np.abs(ret[0, 0, :, :, 2] - conf).max() < 1e-4
+    assert algo.to(torch.device("cuda:0")) is algo
+
+
+def test_warp_frame_functions(cuda):
+    from sd_animation_optical_flow_amd import ofgen, pdcnet_of
+    rng = np.random.default_rng(3)
+    H, W = 50, 40
+    frame = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+    flow = (rng.standard_normal((H, W, 2)) * 4).astype(np.float32)
+    keep = flow.copy()
+    assert np.array_equal(pdcnet_of.warp_frame(frame, flow), WO.warp_frame(frame, flow, "cv2_cubic"))
+    assert np.array_equal(ofgen.warp_frame(frame, flow), WO.warp_frame(frame, flow, "cv2_cubic", convention="raft"))
+    assert np.array_equal(flow, keep)                                     # inputs are not mutated
+    dist = rng.random((H, W)).astype(np.float32) * 9                      # 2-D float map (travel distance)
+    assert np.array_equal(pdcnet_of.warp_frame(dist, flow), WO.warp_frame(dist, flow, "cv2_cubic"))
+    lat = torch.from_numpy(rng.standard_normal((1, 4, 8, 5)).astype(np.float32))
+    big = (rng.standard_normal((64, 40, 2)) * 3).astype(np.float32)
+    out = pdcnet_of.warp_frame_latent(lat, big)
+    assert out.device.type == "cpu" and tuple(out.shape) == (1, 4, 8, 5)
+    assert np.abs(out.numpy() - WO.warp_frame_latent(lat.numpy(), big)).max() < 1e-4
+    out2 = ofgen.warp_frame_latent(lat, big)
+    assert np.abs(out2.numpy() - WO.warp_frame_latent(lat.numpy(), big, convention="raft")).max() < 1e-4
+
+
+def test_masks_and_merges_numpy_surface(cuda):
+    from sd_animation_optical_flow_amd import ofgen
+    rng = np.random.default_rng(4)
+    H, W = 60, 44
+    conf = rng.random((H, W)).astype(np.float32)
+    conf[::6, ::5] = np.float32(0.95)
+    logc = np.log(conf + 1e-3).astype(np.float32)
+    ref_m, ref_lc = MO.generate_mask(conf, logc.copy(), 0.95, 7)
+    lc_in = logc.copy()
+    m, lc_out = ofgen.generate_mask(conf, lc_in, thres=0.95)
+    assert np.array_equal(m, ref_m) and np.array_equal(lc_out, ref_lc)
+    assert lc_out is lc_in and np.array_equal(lc_in, ref_lc)            # the reference mutates its argument (:320)
+    img = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+    assert np.array_equal(ofgen.expand_mask(m, img), MO.expand_mask(m, img))
+    a = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+    b = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+    assert np.array_equal(ofgen.merge_images(a, b, m), MO.merge_images(a, b, m))
+    assert ofgen.mix_propagated_ai_frame(a, b, m, 0.0) is a              # early return (:307-308)
+    assert np.array_equal(ofgen.mix_propagated_ai_frame(a, b, m, 0.7), MO.mix_propagated_ai_frame(a, b, m, 0.7))
+    flow = (rng.standard_normal((H, W, 2)) * 3).astype(np.float32)
+    aux = ofgen.create_mask_aux(H, W, 12.0)
+    travel = np.zeros((H, W), np.float32)
+    for _ in range(3):                                                   # stateful: three consecutive frames
+        dist = MO.travel_distance(flow, conf)
+        ref_mask, travel = MO.confidence_to_mask(conf, flow, dist, travel, 12.0, "cv2_cubic")
+        got = ofgen.confidence_to_mask(conf, flow, dist, aux)
+        assert np.array_equal(got, ref_mask) and np.array_equal(aux.pixel_travel_dist, travel)
+
+
+def test_of_calc_and_raft2(cuda, raft_sd, algo):
+    from sd_animation_optical_flow_amd import ofgen
+    f1, f2 = _pair(5, 100, 90)                       # not a multiple of 8: RAFT_2 pads and does not un-pad
+    r2 = ofgen.RAFT_2(model=raft_sd)
+    flo = r2.calc(f1, f2)
+    ref = RO.raft2_calc(raft_sd, f1, f2)
+    assert flo.shape == ref.shape == (104, 96, 2)
+    assert np.sqrt(((flo - ref) ** 2).sum(-1)).mean() < 1e-3
+    g1, g2 = _pair(6)
+    flow, conf, v, logc = ofgen.of_calc(g1, g2, algo)
+    assert np.array_equal(v, MO.travel_distance(flow, conf))
+
+
+def test_compose_greedy_multi_reference(cuda):
+    from sd_animation_optical_flow_amd import ofgen
+    rng = np.random.default_rng(7)
+    H, W, N = 48, 40, 3
+    fm = np.zeros((N, 1, H, W, 3), np.float32)
+    fm[..., 0:2] = rng.standard_normal((N, 1, H, W, 2)) * 2
+    fm[..., 2] = rng.random((N, 1, H, W))
+    fm[1, 0, 10:30, 5:35, 2] = 0.99                                      # reference 1 wins the first round
+    ai = [rng.integers(0, 256, (H, W, 3), dtype=np.uint8) for _ in range(N)]
+    orig = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+    ref_frame, ref_mask, ref_order = MO.compose(fm, ai, orig, 0.6, warp_mode="cv2_cubic")
+    fm_in = fm.copy()
+    frame, mask2, order = ofgen.compose_warp_and_mask(fm_in, ai, orig, thres=0.6)
+    assert order == ref_order and np.array_equal(frame, ref_frame) and np.array_equal(mask2, ref_mask)
+    assert set(np.unique(fm_in[..., 2])) <= {0.0, 1.0}                   # flow_mat is updated in place (:995, :1023)
+
+
+class _Video:
+    def __init__(self, frames):
+        self.frames = frames
+        self.size_hw = frames[0].shape[:2]
+
+    def get_raw_frame(self, i):
+        return self.frames[i]
+
+
+class _Idx:
+    def __init__(self, idx):
+        self.indices = list(idx)
+
+    def __len__(self):
+        return len(self.indices)
+
+
+def test_pdcnet_aux_pair_cache(algo, tmp_path):
+    from sd_animation_optical_flow_amd import ofgen
+    a, b = _pair(8, 64, 64)
+    c, _ = _pair(9, 64, 64)
+    video = _Video([a, b, c])
+    aux = ofgen.PDCNetAux(algo, str(tmp_path), batch_size=2)
+    mat = aux.calculate_multiple_to_one(video, _Idx([0, 2, 1]), 1)
+    assert mat.shape == (3, 1, 64, 64, 3)
+    assert float(np.abs(mat[2, 0, :, :, 0:2]).max()) == 0.0 and float(mat[2, 0, :, :, 2].min()) == 1.0    # identity pair
+    assert sorted(os.listdir(tmp_path / "pdcnet")) == ["00000-00001.npy", "00002-00001.npy"]
+    on_disk = np.load(tmp_path / "pdcnet" / "00000-00001.npy")
+    assert on_disk.dtype == np.float32 and on_disk.shape == (64, 64, 3) and np.array_equal(on_disk, mat[0, 0])
+    flow, conf, _ = algo.calc(a, b)                                       # (s=0, t=1): source a, target b
+    assert np.abs(on_disk[..., 0:2] - flow).max() < 1e-4 and np.abs(on_disk[..., 2] - conf).max() < 1e-4
+    aux2 = ofgen.PDCNetAux(algo, str(tmp_path), batch_size=2)             # a new instance finds the cache
+    assert aux2.cached_pair == {(0, 1), (2, 1)}
+    assert np.array_equal(aux2.calcualte_single(video, 0, 1), on_disk)
+    pw = aux2.calculate_pairwise(video, _Idx([0, 1]))
+    assert pw.shape == (2, 2, 64, 64, 3) and np.array_equal(pw[0, 1], on_disk)
+    scores = aux2.keyframe_scores(pw)
+    assert np.allclose(scores, MO.keyframe_scores(pw), rtol=1e-6)
