@@ -86,7 +86,7 @@ class PDCNetPlus:
         """`calc_batch` as called at ofgen_keyframe_inpaint.py:594: RGB uint8 tensors [B,H,W,3] on the
         device; returns (flow_est, confidence) whose items assign into numpy slots (:598-599)."""
         flow, conf, _ = self.calc_batch_device(source.contiguous(), target.contiguous(), bgr=False)
-        return flow.cpu(), conf.cpu()
+        return flow.cpu().numpy(), conf.cpu().numpy()
 
 
 def create_of_algo(ckpt) -> PDCNetPlus:
