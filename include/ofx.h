@@ -131,6 +131,7 @@ typedef struct ofx_conv_desc {
     float* out; int ldo;                         /* out[m*ldo + n]; may be NULL for GRU/FLOW epilogues */
     const float* res; int ldres;                 /* residual for EPI_PLAIN, or NULL */
     const float* nmean; const float* nrstd;      /* instance-norm(+ReLU) applied to in0 on load, [B][c0], or NULL */
+    const float* addend; int ldadd;              /* optional pre-activation term: v += addend[m*ldadd + n]       */
     float* aux_z; float* aux_rh; float* aux_h; int ldh;   /* GRU buffers; hidden dim = Cout(Q) */
     float* aux_coords; float* aux_flow4;         /* EPI_FLOW state: coords1 [M][2], flow4 [M][4] */
     long a_zs, w_zs, o_zs; int nz;               /* batched-GEMM mode (nz>1): per-z strides in elements */

@@ -32,6 +32,7 @@ class ConvDesc(C.Structure):
         ("out", C.c_void_p), ("ldo", C.c_int),
         ("res", C.c_void_p), ("ldres", C.c_int),
         ("nmean", C.c_void_p), ("nrstd", C.c_void_p),
+        ("addend", C.c_void_p), ("ldadd", C.c_int),
         ("aux_z", C.c_void_p), ("aux_rh", C.c_void_p), ("aux_h", C.c_void_p), ("ldh", C.c_int),
         ("aux_coords", C.c_void_p), ("aux_flow4", C.c_void_p),
         ("a_zs", C.c_long), ("w_zs", C.c_long), ("o_zs", C.c_long), ("nz", C.c_int),

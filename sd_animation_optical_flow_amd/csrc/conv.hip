@@ -17,12 +17,19 @@
 // Both operands are staged k-contiguous in LDS with a row stride of 36 floats, which makes the
 // per-lane ds_read_b128 fragment reads conflict-free; each b128 read feeds four MFMAs (lane half h
 // supplies k = 8*ks + 4*h + s for s = 0..3 -- the k order inside a chunk is permuted identically for
-// A and B, which leaves the dot product unchanged).  The next k-chunk's global loads are issued
-// before the MFMA block so HBM/L2 latency hides under ~1-4k cycles of matrix work, and the linear
-// block id is remapped so that the N-tiles that share an A tile run on the same XCD (private L2).
+// A and B, which leaves the dot product unchanged).
 //
-// Epilogues fuse bias / folded BatchNorm, activation, residual add, the GRU gate algebra
-// (z, r*h, h = (1-z)h + z*q) and the flow/coords update, so none of those run as separate passes.
+// Pipeline (one barrier per K-chunk, two LDS buffers, two chunks of global loads in flight):
+//     MFMA block on buf[cur]  ->  commit registers (chunk kt+1) to buf[cur^1]  ->  barrier  ->
+//     issue global loads of chunk kt+2
+// The loads are branch-free (addresses clamped into the tensor, padding / K-tail zeroed by a select at
+// commit time), so all 8 of a thread's 16-byte loads are in flight together and have a full MFMA
+// block (1-4k cycles) to land.  The linear block id is remapped so that the N-tiles sharing an A tile
+// run on the same XCD (private L2).
+//
+// Epilogues fuse bias / folded BatchNorm, an optional per-element addend (the loop-invariant part of
+// the GRU convolutions), activation, residual add, the GRU gate algebra (z, r*h, h = (1-z)h + z*q)
+// and the flow/coords update, so none of those run as separate passes.
 #include "ofx_internal.h"
 
 namespace {
@@ -33,6 +40,7 @@ struct ConvK {
     const float* w;
     const float* scale;
     const float* shift;
+    const float* addend;
     float* out;
     const float* res;
     const float* nmean;
@@ -43,42 +51,39 @@ struct ConvK {
     float* aux_coords;
     float* aux_flow4;
     long a_zs, w_zs, o_zs;
-    int ld0, c0, ld1, c1, cin, ldo, ldres, ldh;
+    int ld0, c0, ld1, c1, cin, ldo, ldres, ldh, ldadd;
     int Hin, Win, Hout, Wout, Cout, KW, stride, padH, padW;
     int K, Kpad, M, act;
     int mtiles, ntiles;
     float alpha;
+    unsigned magic_cin, magic_kw;   // ceil(2^32/d) for d = cin, KW (0 when d == 1): k/d = umulhi(k, magic)
+    unsigned kw1_mask;              // all ones when KW == 1 (then tap / KW = tap), else 0
+    int bytes0, bytes1, bytesw;     // extents of the two input segments and of the weight matrix (per z)
 };
 
+#ifndef OFX_SCHED
+#define OFX_SCHED 2
+#endif
 constexpr int kBK = 32;
 constexpr int kLDK = 36;   // LDS row stride in floats: 144 B keeps b128 fragment reads conflict-free
-
-template <int ACT>
-__device__ __forceinline__ float apply_act(float v) {
-    if (ACT == OFX_ACT_RELU) return fmaxf(v, 0.0f);
-    if (ACT == OFX_ACT_SIGMOID) return ofx_sigmoid(v);
-    if (ACT == OFX_ACT_TANH) return tanhf(v);
-    return v;
-}
 
 __device__ __forceinline__ float apply_act_rt(float v, int act) {
     switch (act) {
         case OFX_ACT_RELU: return fmaxf(v, 0.0f);
         case OFX_ACT_SIGMOID: return ofx_sigmoid(v);
-        case OFX_ACT_TANH: return tanhf(v);
+        case OFX_ACT_TANH: return ofx_tanh(v);
         default: return v;
     }
 }
 
-template <int BM, int BN, int WM, int WN, int EPI>
+template <int BM, int BN, int WM, int WN, int EPI, bool NORM>
 __global__ __launch_bounds__(256) void igemm_kernel(const ConvK p) {
     constexpr int TM = WM / 32, TN = WN / 32;
     constexpr int WAVES_N = BN / WN;
     constexpr int A_PER = BM / 32, B_PER = BN / 32;
+    constexpr int STAGE = (BM + BN) * kLDK;
     static_assert((BM / WM) * (BN / WN) == 4, "4 waves per workgroup");
-    __shared__ __attribute__((aligned(16))) float smem[(BM + BN) * kLDK];
-    float* As = smem;
-    float* Bs = smem + BM * kLDK;
+    __shared__ __attribute__((aligned(16))) float smem[2 * STAGE];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -104,67 +109,33 @@ __global__ __launch_bounds__(256) void igemm_kernel(const ConvK p) {
     const float* __restrict__ in1 = p.in1;
     const float* __restrict__ wgt = p.w + (long)z * p.w_zs;
 
+    // ---- buffer descriptors: hardware range checking returns 0 for any offset past the extent, which
+    // implements zero padding, the K tail and the ragged last N tile without address clamps or selects
+    const float* in1s = in1 ? in1 : in0;
+    const int bytes1s = in1 ? p.bytes1 : p.bytes0;
+    const __amdgpu_buffer_rsrc_t rsrcw = __builtin_amdgcn_make_buffer_rsrc((void*)wgt, (short)0, p.bytesw, 0x00020000);
+    constexpr int kOOB = 0x7FFFFFF0;
+
     // ---- per-thread gather coordinates for the A (im2col) tile
     const int kq = tid & 7;    // float4 slot inside the 32-wide k chunk
     const int r0 = tid >> 3;   // 0..31: row inside each 32-row group
     const int HWo = p.Hout * p.Wout;
-    int a_pix[A_PER], a_iy0[A_PER], a_ix0[A_PER], a_b[A_PER];
-    bool a_ok[A_PER];
+    int apix[A_PER], a_iy0[A_PER], a_ix0[A_PER], a_b[NORM ? A_PER : 1];
 #pragma unroll
     for (int i = 0; i < A_PER; ++i) {
-        int m = m0 + r0 + 32 * i;
-        bool ok = m < p.M;
-        int mm = ok ? m : 0;
-        int b = mm / HWo;
-        int rem = mm - b * HWo;
-        int oy = rem / p.Wout;
-        int ox = rem - oy * p.Wout;
-        a_ok[i] = ok;
-        a_b[i] = b;
-        a_pix[i] = b * p.Hin * p.Win;
+        const int m = min(m0 + r0 + 32 * i, p.M - 1);   // rows past M are computed but never stored
+        const int b = m / HWo;
+        const int rem = m - b * HWo;
+        const int oy = rem / p.Wout;
+        const int ox = rem - oy * p.Wout;
+        if (NORM) a_b[i] = b;
         a_iy0[i] = oy * p.stride - p.padH;
         a_ix0[i] = ox * p.stride - p.padW;
+        apix[i] = b * p.Hin * p.Win + a_iy0[i] * p.Win + a_ix0[i];   // may be negative (padding)
     }
-
-    float4 ra[A_PER], rb[B_PER];
-    auto load_tiles = [&](int k0) {
-        const int k = k0 + kq * 4;
-        const bool kok = k < p.K;
-        const int tap = k / p.cin;
-        const int c = k - tap * p.cin;
-        const int ky = tap / p.KW;
-        const int kx = tap - ky * p.KW;
-        const bool seg0 = c < p.c0;
-        const float* base = seg0 ? in0 : in1;
-        const int ld = seg0 ? p.ld0 : p.ld1;
-        const int cc = seg0 ? c : c - p.c0;
+    int browb[B_PER];
 #pragma unroll
-        for (int i = 0; i < A_PER; ++i) {
-            const int iy = a_iy0[i] + ky;
-            const int ix = a_ix0[i] + kx;
-            const bool ok = a_ok[i] && kok && (unsigned)iy < (unsigned)p.Hin && (unsigned)ix < (unsigned)p.Win;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (ok) {
-                v = *reinterpret_cast<const float4*>(base + (long)(a_pix[i] + iy * p.Win + ix) * ld + cc);
-                if (p.nmean != nullptr && seg0) {
-                    const float4 mu = *reinterpret_cast<const float4*>(p.nmean + (long)a_b[i] * p.c0 + cc);
-                    const float4 rs = *reinterpret_cast<const float4*>(p.nrstd + (long)a_b[i] * p.c0 + cc);
-                    v.x = fmaxf((v.x - mu.x) * rs.x, 0.f);
-                    v.y = fmaxf((v.y - mu.y) * rs.y, 0.f);
-                    v.z = fmaxf((v.z - mu.z) * rs.z, 0.f);
-                    v.w = fmaxf((v.w - mu.w) * rs.w, 0.f);
-                }
-            }
-            ra[i] = v;
-        }
-#pragma unroll
-        for (int i = 0; i < B_PER; ++i) {
-            const int n = n0 + r0 + 32 * i;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (n < p.Cout) v = *reinterpret_cast<const float4*>(wgt + (long)n * p.Kpad + k0 + kq * 4);
-            rb[i] = v;
-        }
-    };
+    for (int i = 0; i < B_PER; ++i) browb[i] = (n0 + r0 + 32 * i) * (p.Kpad * 4) + kq * 16;   // rows past Cout fall off the extent
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -175,18 +146,113 @@ __global__ __launch_bounds__(256) void igemm_kernel(const ConvK p) {
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
     const int nk = p.Kpad / kBK;
-    load_tiles(0);
     const int frag_row = lane & 31;
     const int frag_k = (lane >> 5) * 4;
+
+    // ---- pipeline registers (chunk in flight between `issue` and `commit`)
+    float4 ra[A_PER];
+    float4 rb0 = make_float4(0.f, 0.f, 0.f, 0.f), rb1 = rb0, rb2 = rb0, rb3 = rb0;   // named scalars: see OFX_B_* below
+    float4 rmu[NORM ? A_PER : 1], rrs[NORM ? A_PER : 1];
+    unsigned okbits = 0;
+    int voffa[A_PER], voffb[B_PER];
+    int cch_next = 0;
+    bool seg0_next = true;
+
+    // ---- pipeline stages (force-inlined; every staging array is indexed with compile-time constants)
+    auto offsets = [&](int chunk) __attribute__((always_inline)) {
+        // byte offsets of chunk `chunk`: pure VALU, no memory access -> the scheduler interleaves it
+        // with the MFMA block that follows it in the steady-state loop body
+        const int k0 = chunk * kBK;
+        const int k = k0 + kq * 4;
+        const int tap = (int)__umulhi((unsigned)k, p.magic_cin);
+        const int cch = k - tap * p.cin;
+        const int ky = (int)(__umulhi((unsigned)tap, p.magic_kw) + ((unsigned)tap & p.kw1_mask));   // branch-free tap / KW
+        const int kx = tap - ky * p.KW;
+        const bool seg0 = cch < p.c0;
+        const int doff = ky * p.Win + kx;
+        // one multiply per row instead of two per-segment row tables (a select between two arrays
+        // would force both into scratch memory)
+        const int ldb = (seg0 ? p.ld0 : p.ld1) * 4;
+        const int common = doff * ldb + (seg0 ? cch : cch - p.c0) * 4;
+        const bool kval = k < p.K;
+        unsigned bits = 0;
+#pragma unroll
+        for (int i = 0; i < A_PER; ++i) {
+            const int iy = a_iy0[i] + ky;
+            const int ix = a_ix0[i] + kx;
+            // branch-free: the offset is always computed, out-of-image taps get the OOB bits OR-ed in
+            // (a ?: here makes the compiler emit exec-masked branches that split the MFMA basic block)
+            const bool in = kval & ((unsigned)iy < (unsigned)p.Hin) & ((unsigned)ix < (unsigned)p.Win);
+            bits |= (in ? 1u : 0u) << i;
+            voffa[i] = (apix[i] * ldb + common) | (in ? 0 : kOOB);
+        }
+#pragma unroll
+        for (int i = 0; i < B_PER; ++i) voffb[i] = browb[i] + k0 * 4;
+        if (NORM) okbits = (okbits & 0xFFFFu) | (bits << 16);   // [31:16] = chunk being addressed
+        cch_next = cch;
+        seg0_next = seg0;
+    };
+
+    auto issue = [&]() __attribute__((always_inline)) {
+        // 1 VGPR offset per 16-byte load, all 8 in flight together
+        typedef int v4i __attribute__((ext_vector_type(4)));
+        // the segment is uniform per chunk (c0 % 32 == 0): pick the descriptor with scalar selects, no branch
+        const bool seg_u = __builtin_amdgcn_readfirstlane(seg0_next ? 1 : 0) != 0;
+        const __amdgpu_buffer_rsrc_t rsrca =
+            __builtin_amdgcn_make_buffer_rsrc((void*)(seg_u ? in0 : in1s), (short)0, seg_u ? p.bytes0 : bytes1s, 0x00020000);
+#pragma unroll
+        for (int i = 0; i < A_PER; ++i) {
+            v4i t = __builtin_amdgcn_raw_buffer_load_b128(rsrca, voffa[i], 0, 0);
+            ra[i] = *reinterpret_cast<float4*>(&t);
+        }
+        if (NORM) {
+#pragma unroll
+            for (int i = 0; i < A_PER; ++i) {
+                rmu[i] = *reinterpret_cast<const float4*>(p.nmean + (long)a_b[i] * p.c0 + cch_next);
+                rrs[i] = *reinterpret_cast<const float4*>(p.nrstd + (long)a_b[i] * p.c0 + cch_next);
+            }
+            okbits >>= 16;   // the chunk just issued becomes the one the next commit sees
+        }
+#define OFX_B_ISSUE(i) \
+    if constexpr (B_PER > i) { v4i t = __builtin_amdgcn_raw_buffer_load_b128(rsrcw, voffb[i], 0, 0); rb##i = *reinterpret_cast<float4*>(&t); }
+        OFX_B_ISSUE(0) OFX_B_ISSUE(1) OFX_B_ISSUE(2) OFX_B_ISSUE(3)
+#undef OFX_B_ISSUE
+    };
+
+    auto commit = [&](float* As) __attribute__((always_inline)) {
+        float* Bs = As + BM * kLDK;
+#pragma unroll
+        for (int i = 0; i < A_PER; ++i) {
+            float4 v = ra[i];
+            if (NORM) {   // instance norm + ReLU of the producer layer, applied on the fly; padding stays 0
+                v.x = fmaxf((v.x - rmu[i].x) * rrs[i].x, 0.f);
+                v.y = fmaxf((v.y - rmu[i].y) * rrs[i].y, 0.f);
+                v.z = fmaxf((v.z - rmu[i].z) * rrs[i].z, 0.f);
+                v.w = fmaxf((v.w - rmu[i].w) * rrs[i].w, 0.f);
+                if (!((okbits >> i) & 1u)) v = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+            *reinterpret_cast<float4*>(&As[(r0 + 32 * i) * kLDK + kq * 4]) = v;
+        }
+#define OFX_B_COMMIT(i) \
+    if constexpr (B_PER > i) *reinterpret_cast<float4*>(&Bs[(r0 + 32 * i) * kLDK + kq * 4]) = rb##i;
+        OFX_B_COMMIT(0) OFX_B_COMMIT(1) OFX_B_COMMIT(2) OFX_B_COMMIT(3)
+#undef OFX_B_COMMIT
+    };
+
+    // ---- prologue: chunk 0 committed, chunk 1 in flight
+    offsets(0);
+    issue();
+    offsets(min(1, nk - 1));
+    commit(smem);
+    __syncthreads();
+    issue();
+    // ---- steady state, one barrier per chunk:
+    //   [offsets of chunk kt+2 interleaved with the MFMA block on buf[kt&1]] -> commit chunk kt+1 to
+    //   buf[(kt+1)&1] -> barrier -> issue the loads of chunk kt+2 (they land during the next MFMA block)
     for (int kt = 0; kt < nk; ++kt) {
-#pragma unroll
-        for (int i = 0; i < A_PER; ++i)
-            *reinterpret_cast<float4*>(&As[(r0 + 32 * i) * kLDK + kq * 4]) = ra[i];
-#pragma unroll
-        for (int i = 0; i < B_PER; ++i)
-            *reinterpret_cast<float4*>(&Bs[(r0 + 32 * i) * kLDK + kq * 4]) = rb[i];
-        __syncthreads();
-        if (kt + 1 < nk) load_tiles((kt + 1) * kBK);   // in flight during the MFMA block
+        offsets(min(kt + 2, nk - 1));
+        const float* As = smem + (kt & 1) * STAGE;
+        const float* Bs = As + BM * kLDK;
 #pragma unroll
         for (int ks = 0; ks < kBK / 8; ++ks) {
             float4 fa[TM], fb[TN];
@@ -206,7 +272,14 @@ __global__ __launch_bounds__(256) void igemm_kernel(const ConvK p) {
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].w, fb[j].w, acc[i][j], 0, 0, 0);
                 }
         }
+        // chunk kt+1 has had a whole MFMA block to land; on the last iteration this rewrites the idle
+        // buffer with a duplicate that nobody reads
+        commit(smem + ((kt + 1) & 1) * STAGE);
         __syncthreads();
+        issue();
+#if OFX_SCHED & 2
+        __builtin_amdgcn_sched_barrier(0);   // keep the loads ahead of the next MFMA block
+#endif
     }
 
     // ---- epilogue.  C/D layout of the 32x32 MFMA: col (n) = lane&31, row (m) = (e&3) + 8*(e>>2) + 4*(lane>>5)
@@ -224,6 +297,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const ConvK p) {
                 const int m = m0 + wm * WM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
                 if (m >= p.M) continue;
                 float v = acc[i][j][e] * sc + sh;
+                if (p.addend) v += p.addend[(long)m * p.ldadd + n];
                 if (EPI == OFX_EPI_PLAIN) {
                     v = apply_act_rt(v, p.act);
                     if (p.res) v = fmaxf(v + p.res[(long)m * p.ldres + n], 0.f);
@@ -238,7 +312,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const ConvK p) {
                         p.aux_rh[(long)m * hd + c] = v * p.aux_h[(long)m * p.ldh + c];
                     }
                 } else if (EPI == OFX_EPI_GRU_Q) {
-                    const float qv = tanhf(v);
+                    const float qv = ofx_tanh(v);
                     const float zz = p.aux_z[(long)m * p.Cout + n];
                     const long hi = (long)m * p.ldh + n;
                     const float h = p.aux_h[hi];
@@ -259,14 +333,17 @@ __global__ __launch_bounds__(256) void igemm_kernel(const ConvK p) {
 }
 
 template <int BM, int BN, int WM, int WN>
-int launch_tile(const ConvK& k, int epi, int nz, hipStream_t s) {
+int launch_tile(const ConvK& k, int epi, bool norm, int nz, hipStream_t s) {
     dim3 grid((unsigned)(k.mtiles * k.ntiles), (unsigned)nz, 1);
     dim3 block(256, 1, 1);
     switch (epi) {
-        case OFX_EPI_PLAIN: hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, OFX_EPI_PLAIN>), grid, block, 0, s, k); break;
-        case OFX_EPI_GRU_ZR: hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, OFX_EPI_GRU_ZR>), grid, block, 0, s, k); break;
-        case OFX_EPI_GRU_Q: hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, OFX_EPI_GRU_Q>), grid, block, 0, s, k); break;
-        case OFX_EPI_FLOW: hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, OFX_EPI_FLOW>), grid, block, 0, s, k); break;
+        case OFX_EPI_PLAIN:
+            if (norm) hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, OFX_EPI_PLAIN, true>), grid, block, 0, s, k);
+            else hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, OFX_EPI_PLAIN, false>), grid, block, 0, s, k);
+            break;
+        case OFX_EPI_GRU_ZR: hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, OFX_EPI_GRU_ZR, false>), grid, block, 0, s, k); break;
+        case OFX_EPI_GRU_Q: hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, OFX_EPI_GRU_Q, false>), grid, block, 0, s, k); break;
+        case OFX_EPI_FLOW: hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, OFX_EPI_FLOW, false>), grid, block, 0, s, k); break;
         default: return OFX_EINVAL;
     }
     return ofx_launch_status();
@@ -288,17 +365,21 @@ extern "C" int ofx_conv2d_alpha(const ofx_conv_desc* d, float alpha, void* strea
     }
     OFX_REQUIRE(d->B > 0 && d->Hin > 0 && d->Win > 0 && d->Hout > 0 && d->Wout > 0 && d->Cout > 0, OFX_EINVAL);
     OFX_REQUIRE(d->KH > 0 && d->KW > 0 && d->stride > 0, OFX_EINVAL);
-    if (d->nmean) OFX_REQUIRE(d->nrstd && ofx_aligned16(d->nmean) && ofx_aligned16(d->nrstd), OFX_EALIGN);
+    if (d->nmean) {
+        OFX_REQUIRE(d->nrstd && ofx_aligned16(d->nmean) && ofx_aligned16(d->nrstd), OFX_EALIGN);
+        OFX_REQUIRE(d->in1 == nullptr && d->epi == OFX_EPI_PLAIN, OFX_EINVAL);   // fused norm: single segment, plain epilogue
+    }
+    if (d->addend) OFX_REQUIRE(d->ldadd >= d->Cout, OFX_EINVAL);
     const int nz = d->nz > 1 ? d->nz : 1;
 
     ConvK k;
-    k.in0 = d->in0; k.in1 = d->in1; k.w = d->w; k.scale = d->scale; k.shift = d->shift;
+    k.in0 = d->in0; k.in1 = d->in1; k.w = d->w; k.scale = d->scale; k.shift = d->shift; k.addend = d->addend;
     k.out = d->out; k.res = d->res; k.nmean = d->nmean; k.nrstd = d->nrstd;
     k.aux_z = d->aux_z; k.aux_rh = d->aux_rh; k.aux_h = d->aux_h;
     k.aux_coords = d->aux_coords; k.aux_flow4 = d->aux_flow4;
     k.a_zs = nz > 1 ? d->a_zs : 0; k.w_zs = nz > 1 ? d->w_zs : 0; k.o_zs = nz > 1 ? d->o_zs : 0;
     k.ld0 = d->ld0; k.c0 = d->c0; k.ld1 = d->ld1; k.c1 = d->c1; k.cin = d->c0 + d->c1;
-    k.ldo = d->ldo; k.ldres = d->ldres; k.ldh = d->ldh;
+    k.ldo = d->ldo; k.ldres = d->ldres; k.ldh = d->ldh; k.ldadd = d->ldadd;
     k.Hin = d->Hin; k.Win = d->Win; k.Hout = d->Hout; k.Wout = d->Wout; k.Cout = d->Cout;
     k.KW = d->KW; k.stride = d->stride; k.padH = d->padH; k.padW = d->padW;
     k.K = d->KH * d->KW * k.cin;
@@ -308,6 +389,18 @@ extern "C" int ofx_conv2d_alpha(const ofx_conv_desc* d, float alpha, void* strea
     k.M = (int)M;
     k.act = d->act;
     k.alpha = alpha;
+    auto magic = [](int dv) -> unsigned { return dv <= 1 ? 0u : (unsigned)(((1ull << 32) + dv - 1) / dv); };
+    k.magic_cin = magic(k.cin);
+    k.magic_kw = magic(d->KW);
+    k.kw1_mask = d->KW == 1 ? 0xFFFFFFFFu : 0u;
+    // 32-bit byte offsets through buffer descriptors: every operand extent must stay below 2 GiB
+    const long npix_in = (long)d->B * d->Hin * d->Win;
+    const long ext0 = ((npix_in - 1) * d->ld0 + d->c0) * 4, ext1 = d->in1 ? ((npix_in - 1) * d->ld1 + d->c1) * 4 : 0;
+    const long extw = (long)d->Cout * k.Kpad * 4;
+    OFX_REQUIRE(ext0 < (1L << 31) - 64 && ext1 < (1L << 31) - 64 && extw < (1L << 31) - 64, OFX_EINVAL);
+    OFX_REQUIRE(k.Kpad < 65536, OFX_EINVAL);                       // umulhi division is exact in this range
+    if (d->in1) OFX_REQUIRE(d->c0 % kBK == 0, OFX_EALIGN);           // a K chunk never straddles the two segments
+    k.bytes0 = (int)ext0; k.bytes1 = (int)ext1; k.bytesw = (int)extw;
 
     switch (d->epi) {
         case OFX_EPI_PLAIN:
@@ -346,16 +439,17 @@ extern "C" int ofx_conv2d_alpha(const ofx_conv_desc* d, float alpha, void* strea
     k.mtiles = (int)((M + bm - 1) / bm);
     k.ntiles = (d->Cout + bn - 1) / bn;
     hipStream_t s = (hipStream_t)stream;
+    const bool norm = d->nmean != nullptr;
     const char* pname = nz > 1 ? "igemm_corr_volume"
                        : d->epi == OFX_EPI_GRU_ZR ? "igemm_conv_gru_zr"
                        : d->epi == OFX_EPI_GRU_Q  ? "igemm_conv_gru_q"
                        : d->epi == OFX_EPI_FLOW   ? "igemm_conv_flow"
                                                   : "igemm_conv";
     OfxProfScope prof(pname, s);
-    if (bm == 128 && bn == 128) return launch_tile<128, 128, 64, 64>(k, d->epi, nz, s);
-    if (bm == 128 && bn == 64) return launch_tile<128, 64, 64, 32>(k, d->epi, nz, s);
-    if (bm == 128 && bn == 32) return launch_tile<128, 32, 32, 32>(k, d->epi, nz, s);
-    if (bm == 64 && bn == 64) return launch_tile<64, 64, 32, 32>(k, d->epi, nz, s);
+    if (bm == 128 && bn == 128) return launch_tile<128, 128, 64, 64>(k, d->epi, norm, nz, s);
+    if (bm == 128 && bn == 64) return launch_tile<128, 64, 64, 32>(k, d->epi, norm, nz, s);
+    if (bm == 128 && bn == 32) return launch_tile<128, 32, 32, 32>(k, d->epi, norm, nz, s);
+    if (bm == 64 && bn == 64) return launch_tile<64, 64, 32, 32>(k, d->epi, norm, nz, s);
     return OFX_EINVAL;
 }
 

@@ -135,9 +135,10 @@ __global__ __launch_bounds__(256) void upsample_kernel(const float* __restrict__
     float den = 0.f;
 #pragma unroll
     for (int k = 0; k < 9; ++k) {
-        lg[k] = expf(lg[k] - mx);
+        lg[k] = __expf(lg[k] - mx);   // v_exp_f32 path (~2 ulp): 576 exponentials per coarse pixel made this kernel VALU-bound
         den += lg[k];
     }
+    const float inv_den = __builtin_amdgcn_rcpf(den);
     float ax = 0.f, ay = 0.f;
 #pragma unroll
     for (int k = 0; k < 9; ++k) {
@@ -148,7 +149,7 @@ __global__ __launch_bounds__(256) void upsample_kernel(const float* __restrict__
             fx = 8.0f * (c.x - (float)xx);    // 8 * (coords1 - coords0)
             fy = 8.0f * (c.y - (float)yy);
         }
-        const float wgt = lg[k] / den;
+        const float wgt = lg[k] * inv_den;
         ax += wgt * fx;
         ay += wgt * fy;
     }

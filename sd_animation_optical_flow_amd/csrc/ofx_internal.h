@@ -42,6 +42,10 @@ int ofx_local_corr_launch(const float* f1, const float* f2, const float* coords,
                           long sc, long sp, int B, int H1, int W1, int H2, int W2, int C, int N, int r, float scale,
                           float cscale, hipStream_t s);
 int ofx_corr_pool_launch(const float* l0, float* l1, float* l2, float* l3, int B, int h, int w, int levels, hipStream_t s);
+// mask_bits.hip: binary threshold/edge source -> elliptical dilation on bit planes
+int ofx_mask_bits_launch(int src, const float* conf, float* log_conf, const uint8_t* image, const uint8_t* or_mask,
+                         uint8_t* out, int B, int H, int W, float thres, int edge_thres, int r, const signed char* hw,
+                         const char* name, hipStream_t s);
 int ofx_init_state(float* coords1, float* flow4, float* hx, int ldh, int flow_off, int B, int h, int w, hipStream_t s);
 int ofx_coords_to_flow(const float* coords1, float* flow, int B, int h, int w, hipStream_t s);
 
@@ -50,7 +54,15 @@ int ofx_coords_to_flow(const float* coords1, float* flow, int B, int h, int w, h
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-__device__ __forceinline__ float ofx_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
+// Gate non-linearities of the conv epilogues on the hardware transcendental units (v_exp_f32 / v_rcp_f32,
+// <= 2 ulp each; absolute error ~2e-7, far inside the 1e-3 px flow tolerance).  The libm forms (expf, a
+// correctly rounded divide, OCML tanhf) cost 40-60 VALU instructions per element and showed up as a
+// 25 % epilogue tax on the GRU convolutions.
+__device__ __forceinline__ float ofx_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
+__device__ __forceinline__ float ofx_tanh(float x) {
+    const float t = __expf(2.0f * fminf(fmaxf(x, -15.0f), 15.0f));
+    return (t - 1.0f) * __builtin_amdgcn_rcpf(t + 1.0f);
+}
 
 // Keys cubic weights, A = -0.75 (same polynomial form as OpenCV's interpolateCubic)
 __device__ __forceinline__ void ofx_cubic_coeffs(float t, float w[4]) {

@@ -50,8 +50,16 @@ constexpr int HD = 128;      // hidden dim (raft.py:38)
 constexpr int CD = 128;      // context dim (raft.py:39)
 constexpr int FD = 256;      // feature dim (raft.py:54)
 constexpr int LEVELS = 4, RADIUS = 4, CORR_CH = LEVELS * (2 * RADIUS + 1) * (2 * RADIUS + 1);   // 324
-constexpr int HX_LD = HD + CD + 128;   // [h | inp | motion(126) | flow(2)] = 384
-constexpr int FLOW_OFF = HX_LD - 2;
+// hx row = [h(128) | motion(126) flow(2) | inp(128)] = 384 floats.  The recurrent part (h, motion) is
+// contiguous so the per-iteration GRU convolutions read 256 channels; `inp` (the context features) is
+// loop-invariant: its contribution to the six GRU convolutions (+ their biases) is computed ONCE per
+// forward into `gadd` and enters the per-iteration convolutions as an epilogue addend -- one third of
+// the GRU FLOPs leaves the 20-iteration loop.
+constexpr int HX_LD = HD + 128 + CD;
+constexpr int MOT_OFF = HD;
+constexpr int FLOW_OFF = MOT_OFF + 126;
+constexpr int INP_OFF = HD + 128;
+constexpr int GADD_LD = 2 * (2 * HD + HD);   // [zr1(256) | q1(128) | zr2(256) | q2(128)]
 constexpr int ENC_CHUNK = 16;          // images per encoder pass (bounds the activation workspace)
 
 struct Carver {
@@ -93,7 +101,8 @@ const HostTensor* find(const std::map<std::string, HostTensor>& sd, const std::s
 // extra output scale as in `.25 * self.mask(net)`, update.py:135)
 int add_conv(ofx_raft* r, const std::map<std::string, HostTensor>& sd, const std::string& name,
              const std::string& store_as, int cin_pad, const std::string& bn, float out_scale,
-             std::vector<float>* append_w = nullptr, std::vector<float>* append_shift = nullptr) {
+             std::vector<float>* append_w = nullptr, std::vector<float>* append_shift = nullptr,
+             const std::vector<int>* chan_sel = nullptr, bool with_bias = true) {
     const HostTensor* w = find(sd, name + ".weight");
     const HostTensor* b = find(sd, name + ".bias");
     if (!w || !b || w->ndim != 4 || b->ndim != 1 || b->shape[0] != w->shape[0]) return OFX_EKEY;
@@ -102,12 +111,36 @@ int add_conv(ofx_raft* r, const std::map<std::string, HostTensor>& sd, const std
     c.cin = (int)w->shape[1];
     c.kh = (int)w->shape[2];
     c.kw = (int)w->shape[3];
+    const float* wdata = w->data;
+    std::vector<float> wsel;
+    if (chan_sel) {   // keep a subset of the input channels, in the given order
+        const int full = c.cin, taps = c.kh * c.kw;
+        c.cin = (int)chan_sel->size();
+        wsel.resize((size_t)c.cout * c.cin * taps);
+        for (int o = 0; o < c.cout; ++o)
+            for (int ci = 0; ci < c.cin; ++ci) {
+                const int src = (*chan_sel)[ci];
+                if (src < 0 || src >= full) return OFX_EKEY;
+                for (int t = 0; t < taps; ++t)
+                    wsel[((size_t)o * c.cin + ci) * taps + t] = w->data[((size_t)o * full + src) * taps + t];
+            }
+        wdata = wsel.data();
+    }
     c.cin_pad = cin_pad > 0 ? cin_pad : ((c.cin + 3) / 4) * 4;
     if (c.cin_pad < c.cin) return OFX_EKEY;
     c.kpad = ofx_pack_conv_weight(nullptr, c.cout, c.cin, c.kh, c.kw, c.cin_pad, nullptr);
     if (c.kpad < 0) return (int)c.kpad;
     std::vector<float> pw((size_t)c.cout * c.kpad);
-    ofx_pack_conv_weight(w->data, c.cout, c.cin, c.kh, c.kw, c.cin_pad, pw.data());
+    ofx_pack_conv_weight(wdata, c.cout, c.cin, c.kh, c.kw, c.cin_pad, pw.data());
+    std::vector<float> zero_bias;
+    if (!with_bias) zero_bias.assign(c.cout, 0.f);
+    HostTensor bz;
+    if (!with_bias) {
+        bz.data = zero_bias.data();
+        bz.ndim = 1;
+        bz.shape[0] = c.cout;
+        b = &bz;
+    }
     std::vector<float> scale, shift(c.cout);
     if (!bn.empty()) {
         const HostTensor* g = find(sd, bn + ".weight");
@@ -170,25 +203,44 @@ int build_encoder(ofx_raft* r, const std::map<std::string, HostTensor>& sd, cons
 }
 
 int build_gru(ofx_raft* r, const std::map<std::string, HostTensor>& sd, const std::string& tag) {
-    // z and r share their input: one conv with Cout = 256 ([convz ; convr] rows)
-    std::vector<float> w, sh;
-    int st = add_conv(r, sd, "update_block.gru.convz" + tag, "gru.z" + tag, 0, "", 1.f, &w, &sh);
-    if (st) return st;
-    st = add_conv(r, sd, "update_block.gru.convr" + tag, "gru.r" + tag, 0, "", 1.f, &w, &sh);
-    if (st) return st;
-    ConvW c = r->convs["gru.z" + tag];
-    c.cout *= 2;
-    st = upload(r, w, &c.w);
-    if (st) return st;
-    st = upload(r, sh, &c.shift);
-    if (st) return st;
-    r->convs["gru.zr" + tag] = c;
-    return add_conv(r, sd, "update_block.gru.convq" + tag, "gru.q" + tag, 0, "", 1.f);
+    // The reference's GRU input is cat([h, x]) with x = cat([inp, motion]) (update.py:131-133): input
+    // channels 0..127 = h, 128..255 = inp, 256..383 = motion.  Split every GRU conv into
+    //   * a recurrent part over [h | motion] (256 channels, no bias) evaluated every iteration, and
+    //   * a loop-invariant part over [inp] (128 channels, with the bias) evaluated once per forward.
+    // z and r share their input: one conv with Cout = 256 ([convz ; convr] rows).
+    std::vector<int> rec, inv;
+    for (int c = 0; c < HD; ++c) rec.push_back(c);
+    for (int c = 0; c < 128; ++c) rec.push_back(HD + CD + c);
+    for (int c = 0; c < CD; ++c) inv.push_back(HD + c);
+    for (int part = 0; part < 2; ++part) {
+        const std::vector<int>* sel = part == 0 ? &rec : &inv;
+        const bool bias = part == 1;
+        const std::string sfx = part == 0 ? "" : ".inp";
+        std::vector<float> w, sh;
+        int st = add_conv(r, sd, "update_block.gru.convz" + tag, "gru.z" + tag + sfx, 0, "", 1.f, &w, &sh, sel, bias);
+        if (st) return st;
+        st = add_conv(r, sd, "update_block.gru.convr" + tag, "gru.r" + tag + sfx, 0, "", 1.f, &w, &sh, sel, bias);
+        if (st) return st;
+        ConvW c = r->convs["gru.z" + tag + sfx];
+        c.cout *= 2;
+        st = upload(r, w, &c.w);
+        if (st) return st;
+        if (bias) {
+            st = upload(r, sh, &c.shift);
+            if (st) return st;
+        }
+        r->convs["gru.zr" + tag + sfx] = c;
+        st = add_conv(r, sd, "update_block.gru.convq" + tag, "gru.q" + tag + sfx, 0, "", 1.f, nullptr, nullptr, sel, bias);
+        if (st) return st;
+    }
+    return 0;
 }
 
 struct Launcher {
     hipStream_t s;
     int st = 0;
+    const float* addend = nullptr;   // consumed (and cleared) by the next conv() call
+    int ldadd = 0;
     // generic conv launch; all pointer plumbing in one place
     void conv(const ConvW& c, const float* in0, int ld0, int c0, const float* in1, int ld1, int c1, float* out, int ldo,
               int B, int Hin, int Win, int stride, int act, int epi = OFX_EPI_PLAIN, const float* res = nullptr,
@@ -206,6 +258,8 @@ struct Launcher {
         d.out = out; d.ldo = ldo;
         d.res = res; d.ldres = ldres;
         d.nmean = nmean; d.nrstd = nrstd;
+        d.addend = addend; d.ldadd = ldadd;
+        addend = nullptr; ldadd = 0;
         d.aux_z = aux_z; d.aux_rh = aux_rh; d.aux_h = aux_h; d.ldh = ldh;
         d.aux_coords = aux_coords; d.aux_flow4 = aux_flow4;
         d.B = B; d.Hin = Hin; d.Win = Win;
@@ -229,7 +283,7 @@ struct EncBufs {
 
 // --------------------------------------------------------------------------------------------
 static int run_encoder(ofx_raft* r, const std::string& enc, bool bn, const uint8_t* imgs, int n, int H, int W,
-                       int bgr, const EncBufs& eb, float* out, int out_ld, bool split_tanh_relu, hipStream_t s) {
+                       int bgr, const EncBufs& eb, float* out, int out_ld, bool split_tanh_relu, int relu_off, hipStream_t s) {
     // `out`: [n*h*w][out_ld]; fnet writes 256 channels; cnet writes tanh(0:128) | relu(128:256)
     Launcher L{s};
     const int H2 = H / 2, W2 = W / 2, H4 = H / 4, W4 = W / 4, H8 = H / 8, W8 = W / 8;
@@ -296,7 +350,7 @@ static int run_encoder(ofx_raft* r, const std::string& enc, bool bn, const uint8
         // net = tanh(cnet[:, :128]), inp = relu(cnet[:, 128:256])  (raft.py:111-114)
         L.conv(C("conv2"), X, 128, 128, nullptr, 0, 0, out, out_ld, n, hin, win, 1, OFX_ACT_TANH, OFX_EPI_PLAIN, nullptr, 0,
                nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr, 0, HD);
-        L.conv(C("conv2"), X, 128, 128, nullptr, 0, 0, out + HD, out_ld, n, hin, win, 1, OFX_ACT_RELU, OFX_EPI_PLAIN, nullptr,
+        L.conv(C("conv2"), X, 128, 128, nullptr, 0, 0, out + relu_off, out_ld, n, hin, win, 1, OFX_ACT_RELU, OFX_EPI_PLAIN, nullptr,
                0, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr, HD, CD);
     }
     return L.st;
@@ -307,7 +361,7 @@ struct RaftWs {
     EncBufs eb;
     float *fmap1, *fmap2, *f2l[LEVELS];
     float* pyr[LEVELS];
-    float *hx, *coords1, *flow4, *corr, *c1, *corflo, *f1, *z, *rh, *mask;
+    float *hx, *gadd, *coords1, *flow4, *corr, *c1, *corflo, *f1, *z, *rh, *mask;
     size_t bytes;
 };
 
@@ -337,6 +391,7 @@ static RaftWs carve(void* base, size_t cap, int B, int H, int W, int flags) {
         for (int l = 0; l < LEVELS; ++l) w.pyr[l] = c.take((size_t)M * (h >> l) * (wd >> l));
     }
     w.hx = c.take((size_t)M * HX_LD);
+    w.gadd = c.take((size_t)M * GADD_LD);
     w.coords1 = c.take((size_t)M * 2);
     w.flow4 = c.take((size_t)M * 4);
     w.corr = c.take((size_t)M * CORR_CH);
@@ -433,24 +488,24 @@ int ofx_raft_forward(ofx_raft* r, const uint8_t* image1, const uint8_t* image2, 
     for (int i0 = 0; i0 < n1 && !st; i0 += ENC_CHUNK) {
         const int n = std::min(ENC_CHUNK, n1 - i0);
         st = run_encoder(r, "fnet", false, image1 + i0 * img_bytes, n, H, W, bgr, ws.eb, ws.fmap1 + (long)i0 * N * FD, FD,
-                         false, s);
+                         false, 0, s);
     }
     for (int i0 = 0; i0 < n2 && !st; i0 += ENC_CHUNK) {
         const int n = std::min(ENC_CHUNK, n2 - i0);
         st = run_encoder(r, "fnet", false, image2 + i0 * img_bytes, n, H, W, bgr, ws.eb, ws.fmap2 + (long)i0 * N * FD, FD,
-                         false, s);
+                         false, 0, s);
     }
-    // ---- context encoder on image1 -> hx[:, 0:128] = tanh, hx[:, 128:256] = relu
+    // ---- context encoder on image1 -> hx[:, 0:128] = tanh (net), hx[:, 256:384] = relu (inp)
     if (sh1) {
-        if (!st) st = run_encoder(r, "cnet", true, image1, 1, H, W, bgr, ws.eb, ws.hx, HX_LD, true, s);
+        if (!st) st = run_encoder(r, "cnet", true, image1, 1, H, W, bgr, ws.eb, ws.hx, HX_LD, true, INP_OFF, s);
         for (int k = 1; k < B && !st; ++k)   // one shared image1: replicate its context rows
-            OFX_HIP_CHECK(hipMemcpy2DAsync(ws.hx + (long)k * N * HX_LD, HX_LD * sizeof(float), ws.hx, HX_LD * sizeof(float),
-                                           (HD + CD) * sizeof(float), (size_t)N, hipMemcpyDeviceToDevice, s));
+            OFX_HIP_CHECK(hipMemcpyAsync(ws.hx + (long)k * N * HX_LD, ws.hx, (size_t)N * HX_LD * sizeof(float),
+                                         hipMemcpyDeviceToDevice, s));
     } else {
         for (int i0 = 0; i0 < B && !st; i0 += ENC_CHUNK) {
             const int n = std::min(ENC_CHUNK, B - i0);
             st = run_encoder(r, "cnet", true, image1 + i0 * img_bytes, n, H, W, bgr, ws.eb, ws.hx + (long)i0 * N * HX_LD,
-                             HX_LD, true, s);
+                             HX_LD, true, INP_OFF, s);
         }
     }
     if (st) return st;
@@ -477,6 +532,15 @@ int ofx_raft_forward(ofx_raft* r, const uint8_t* image1, const uint8_t* image2, 
 
     st = ofx_init_state(ws.coords1, ws.flow4, ws.hx, HX_LD, FLOW_OFF, B, h, w, s);
     if (st) return st;
+    {   // loop-invariant GRU terms: conv(W[:, inp], inp) + bias for z|r and q of both passes
+        Launcher G{s};
+        const char* names[4] = {"gru.zr1.inp", "gru.q1.inp", "gru.zr2.inp", "gru.q2.inp"};
+        const int offs[4] = {0, 2 * HD, 3 * HD, 5 * HD};
+        for (int i = 0; i < 4; ++i)
+            G.conv(r->convs[names[i]], ws.hx + INP_OFF, HX_LD, CD, nullptr, 0, 0, ws.gadd + offs[i], GADD_LD, B, h, w, 1,
+                   OFX_ACT_NONE);
+        if (G.st) return G.st;
+    }
 
     Launcher L{s};
     auto C = [&](const char* k) -> const ConvW& { return r->convs[k]; };
@@ -499,14 +563,17 @@ int ofx_raft_forward(ofx_raft* r, const uint8_t* image1, const uint8_t* image2, 
         L.conv(C("convc2"), ws.c1, 256, 256, nullptr, 0, 0, ws.corflo, 256, B, h, w, 1, OFX_ACT_RELU);
         L.conv(C("convf1"), ws.flow4, 4, 4, nullptr, 0, 0, ws.f1, 128, B, h, w, 1, OFX_ACT_RELU);
         L.conv(C("convf2"), ws.f1, 128, 128, nullptr, 0, 0, ws.corflo + 192, 256, B, h, w, 1, OFX_ACT_RELU);
-        L.conv(C("conv"), ws.corflo, 256, 256, nullptr, 0, 0, ws.hx + HD + CD, HX_LD, B, h, w, 1, OFX_ACT_RELU);
+        L.conv(C("conv"), ws.corflo, 256, 256, nullptr, 0, 0, ws.hx + MOT_OFF, HX_LD, B, h, w, 1, OFX_ACT_RELU);
         // SepConvGRU (update.py:44-60): horizontal then vertical pass
         for (int pass = 1; pass <= 2; ++pass) {
             const char* zr = pass == 1 ? "gru.zr1" : "gru.zr2";
             const char* q = pass == 1 ? "gru.q1" : "gru.q2";
-            L.conv(C(zr), ws.hx, HX_LD, HX_LD, nullptr, 0, 0, nullptr, 0, B, h, w, 1, OFX_ACT_NONE, OFX_EPI_GRU_ZR, nullptr, 0,
+            const float* g = ws.gadd + (pass - 1) * (3 * HD);
+            L.addend = g; L.ldadd = GADD_LD;
+            L.conv(C(zr), ws.hx, HX_LD, 2 * HD, nullptr, 0, 0, nullptr, 0, B, h, w, 1, OFX_ACT_NONE, OFX_EPI_GRU_ZR, nullptr, 0,
                    nullptr, nullptr, ws.z, ws.rh, ws.hx, HX_LD);
-            L.conv(C(q), ws.rh, HD, HD, ws.hx + HD, HX_LD, HX_LD - HD, nullptr, 0, B, h, w, 1, OFX_ACT_NONE, OFX_EPI_GRU_Q,
+            L.addend = g + 2 * HD; L.ldadd = GADD_LD;
+            L.conv(C(q), ws.rh, HD, HD, ws.hx + MOT_OFF, HX_LD, 128, nullptr, 0, B, h, w, 1, OFX_ACT_NONE, OFX_EPI_GRU_Q,
                    nullptr, 0, nullptr, nullptr, ws.z, nullptr, ws.hx, HX_LD);
         }
         // flow head (update.py:6-14) + coords1 += delta (raft.py:131) in the epilogue

@@ -271,6 +271,170 @@ __global__ __launch_bounds__(256) void warp_kernel(const T* __restrict__ frame, 
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// fast path: uint8, 3 channels (the AI key frame), 4 consecutive output pixels per thread.
+// The generic kernel issues 12 byte-loads + 3 byte-stores per pixel; here a row of taps is ONE unaligned
+// 8- or 12-byte load (the taps of a row are adjacent in memory) and the 4 results are one 12-byte store,
+// so the kernel is limited by HBM bytes instead of load/store instruction issue.
+// ------------------------------------------------------------------------------------------
+struct __attribute__((packed, aligned(1))) PackedU2 { uint32_t a, b; };
+struct __attribute__((packed, aligned(1))) PackedU3 { uint32_t a, b, c; };
+
+// N adjacent pixels (3 bytes each) of row yy starting at column xx; zeros outside the image
+template <int N>
+__device__ __forceinline__ void fetch_run_u8c3(const uint8_t* __restrict__ img, long img_bytes, int H, int W, int yy, int xx,
+                                               uint8_t (&px)[N][3]) {
+    static_assert(N == 2 || N == 4, "runs of 2 (bilinear) or 4 (cubic) pixels");
+#pragma unroll
+    for (int i = 0; i < N; ++i) px[i][0] = px[i][1] = px[i][2] = 0;
+    if ((unsigned)yy >= (unsigned)H) return;
+    const long off = ((long)yy * W + xx) * 3;
+    constexpr int kLoadBytes = N == 2 ? 8 : 12;
+    if (xx >= 0 && xx + N <= W && off + kLoadBytes <= img_bytes) {
+        uint32_t w[3];
+        if (N == 2) {
+            const PackedU2 v = *reinterpret_cast<const PackedU2*>(img + off);
+            w[0] = v.a; w[1] = v.b; w[2] = 0;
+        } else {
+            const PackedU3 v = *reinterpret_cast<const PackedU3*>(img + off);
+            w[0] = v.a; w[1] = v.b; w[2] = v.c;
+        }
+#pragma unroll
+        for (int i = 0; i < N; ++i)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const int byte = i * 3 + c;
+                px[i][c] = (uint8_t)((w[byte >> 2] >> ((byte & 3) * 8)) & 0xFFu);
+            }
+    } else {
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            const int x = xx + i;
+            if ((unsigned)x < (unsigned)W) {
+                const uint8_t* q = img + ((long)yy * W + x) * 3;
+                px[i][0] = q[0]; px[i][1] = q[1]; px[i][2] = q[2];
+            }
+        }
+    }
+}
+
+template <int MODE>
+__device__ __forceinline__ void warp_pixel_u8c3(const uint8_t* __restrict__ img, long img_bytes, int H, int W, float mx, float my,
+                                                const short* __restrict__ tabi, uint8_t (&dst)[3]) {
+    if (MODE == OFX_WARP_BILINEAR) {
+        const float x0f = floorf(mx), y0f = floorf(my);
+        const float fx = mx - x0f, fy = my - y0f;
+        const int x0 = (int)fminf(fmaxf(x0f, -1.0e6f), 1.0e6f);
+        const int y0 = (int)fminf(fmaxf(y0f, -1.0e6f), 1.0e6f);
+        const float w00 = (1.f - fx) * (1.f - fy), w01 = fx * (1.f - fy);
+        const float w10 = (1.f - fx) * fy, w11 = fx * fy;
+        // Branch-free taps: ONE unconditional 8-byte load per row from a position clamped into the frame
+        // (so all 8 row loads of a thread's 4 pixels are in flight together), then the two pixels are
+        // extracted with shifts and zeroed where the true tap lies outside the image.
+        uint8_t r0[2][3], r1[2][3];
+        const int xc = min(max(x0, 0), W - 2);
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr) {
+            const int yy = y0 + rr;
+            const bool yok = (unsigned)yy < (unsigned)H;
+            const long off = ((long)min(max(yy, 0), H - 1) * W + xc) * 3;
+            const long start = off + 8 <= img_bytes ? off : img_bytes - 8;      // last pixel pair of the frame
+            const PackedU2 v = *reinterpret_cast<const PackedU2*>(img + start);
+            const unsigned long long bits = ((((unsigned long long)v.b) << 32) | v.a) >> ((int)(off - start) * 8);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int col = x0 + i;
+                const bool ok = yok && (unsigned)col < (unsigned)W;
+                const int sh = ok ? 24 * (col - xc) : 0;                         // col - xc is 0 or 1 when ok
+                const unsigned px3 = ok ? (unsigned)(bits >> sh) & 0xFFFFFFu : 0u;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) (rr == 0 ? r0 : r1)[i][c] = (uint8_t)((px3 >> (8 * c)) & 0xFFu);
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            float acc = (float)r0[0][c] * w00;       // same evaluation order as the generic kernel
+            acc = acc + (float)r0[1][c] * w01;
+            acc = acc + (float)r1[0][c] * w10;
+            acc = acc + (float)r1[1][c] * w11;
+            dst[c] = st_px<uint8_t>(acc);
+        }
+    } else {   // OFX_WARP_CV2_CUBIC
+        const float lim = 1.0e9f;
+        const int sx = (int)rintf(fminf(fmaxf(mx * (float)kTabSize, -lim), lim));
+        const int sy = (int)rintf(fminf(fmaxf(my * (float)kTabSize, -lim), lim));
+        int ix = sx >> 5, iy = sy >> 5;
+        ix = min(max(ix, -32768), 32767);
+        iy = min(max(iy, -32768), 32767);
+        const short* w = tabi + ((sy & (kTabSize - 1)) * kTabSize + (sx & (kTabSize - 1))) * 16;
+        int acc[3] = {0, 0, 0};
+#pragma unroll
+        for (int k1 = 0; k1 < 4; ++k1) {
+            uint8_t row[4][3];
+            fetch_run_u8c3<4>(img, img_bytes, H, W, iy - 1 + k1, ix - 1, row);
+#pragma unroll
+            for (int k2 = 0; k2 < 4; ++k2) {
+                const int wv = w[k1 * 4 + k2];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) acc[c] += (int)row[k2][c] * wv;
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const int v = (acc[c] + (1 << (kCoefBits - 1))) >> kCoefBits;
+            dst[c] = (uint8_t)min(max(v, 0), 255);
+        }
+    }
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256) void warp_u8c3_x4_kernel(const uint8_t* __restrict__ frame, long fbs, const float* __restrict__ flow,
+                                                           uint8_t* __restrict__ out, int H, int W, long ngroups, float sign,
+                                                           const short* __restrict__ tabi) {
+    const int W4 = (W + 3) >> 2;
+    const long img_bytes = (long)H * W * 3;
+    for (long g = (long)blockIdx.x * blockDim.x + threadIdx.x; g < ngroups; g += (long)gridDim.x * blockDim.x) {
+        const int xg = (int)(g % W4);
+        const long row = g / W4;            // b*H + y
+        const int y = (int)(row % H);
+        const long b = row / H;
+        const int x = xg * 4;
+        const int npx = min(4, W - x);
+        const long p0 = row * W + x;
+        const uint8_t* img = frame + b * fbs;
+        uint8_t res[4][3];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (j < npx) {
+                const float2 f = reinterpret_cast<const float2*>(flow)[p0 + j];
+                warp_pixel_u8c3<MODE>(img, img_bytes, H, W, map_coord(x + j, f.x, sign), map_coord(y, f.y, sign), tabi, res[j]);
+            } else {
+                res[j][0] = res[j][1] = res[j][2] = 0;
+            }
+        }
+        uint8_t* o = out + p0 * 3;
+        if (npx == 4 && (((uintptr_t)o) & 3u) == 0) {
+            uint32_t w[3];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                uint32_t v = 0;
+#pragma unroll
+                for (int bb = 0; bb < 4; ++bb) {
+                    const int byte = k * 4 + bb;
+                    v |= (uint32_t)res[byte / 3][byte % 3] << (bb * 8);
+                }
+                w[k] = v;
+            }
+            PackedU3 st{w[0], w[1], w[2]};
+            *reinterpret_cast<PackedU3*>(o) = st;
+        } else {
+            for (int j = 0; j < npx; ++j) {
+                o[j * 3 + 0] = res[j][0]; o[j * 3 + 1] = res[j][1]; o[j * 3 + 2] = res[j][2];
+            }
+        }
+    }
+}
+
 template <typename T, int C>
 int launch_warp_c(const T* frame, long fbs, const float* flow, T* out, int B, int H, int W, int mode,
                   float sign, hipStream_t s) {
@@ -306,6 +470,18 @@ int launch_warp(const T* frame, long fbs, const float* flow, T* out, int B, int 
         if (st) return st;
     }
     hipStream_t s = (hipStream_t)stream;
+    if (sizeof(T) == 1 && C == 3 && mode != OFX_WARP_BICUBIC && W >= 4 && H >= 2) {
+        const long ngroups = (long)B * H * ((W + 3) / 4);
+        const int grid = (int)std::min<long>((ngroups + 255) / 256, 256L * 64);
+        OfxProfScope prof("warp_u8", s);
+        if (mode == OFX_WARP_BILINEAR)
+            hipLaunchKernelGGL((warp_u8c3_x4_kernel<OFX_WARP_BILINEAR>), dim3(grid), dim3(256), 0, s, (const uint8_t*)frame, fbs, flow,
+                               (uint8_t*)out, H, W, ngroups, sign, g_tabs.i);
+        else
+            hipLaunchKernelGGL((warp_u8c3_x4_kernel<OFX_WARP_CV2_CUBIC>), dim3(grid), dim3(256), 0, s, (const uint8_t*)frame, fbs, flow,
+                               (uint8_t*)out, H, W, ngroups, sign, g_tabs.i);
+        return ofx_launch_status();
+    }
     switch (C) {
         case 1: return launch_warp_c<T, 1>(frame, fbs, flow, out, B, H, W, mode, sign, s);
         case 2: return launch_warp_c<T, 2>(frame, fbs, flow, out, B, H, W, mode, sign, s);
@@ -604,11 +780,10 @@ int ofx_generate_mask(const float* conf, float* log_conf, uint8_t* mask, int B, 
                       int ksize, int cmp_gt, void* stream) {
     OFX_REQUIRE(conf && mask && B > 0 && H > 0 && W > 0, OFX_EINVAL);
     OFX_REQUIRE(ksize >= 1 && ksize <= kMaxK && (ksize & 1), OFX_EINVAL);
-    DilateArgs a{};
-    a.conf = conf; a.log_conf = log_conf; a.out = mask; a.H = H; a.W = W; a.thres = thres;
-    a.el = make_ellipse(ksize);
-    hipStream_t s = (hipStream_t)stream;
-    return cmp_gt ? launch_dilate<SRC_CONF_NGT>(a, B, s, "generate_mask") : launch_dilate<SRC_CONF_LT>(a, B, s, "generate_mask");
+    // binary morphology runs on bit planes (mask_bits.hip)
+    const Ellipse el = make_ellipse(ksize);
+    return ofx_mask_bits_launch(cmp_gt ? SRC_CONF_NGT : SRC_CONF_LT, conf, log_conf, nullptr, nullptr, mask, B, H, W, thres, 0,
+                                el.r, el.hw, "generate_mask", (hipStream_t)stream);
 }
 
 int ofx_dilate_u8(const uint8_t* in, uint8_t* out, int B, int H, int W, int ksize, void* stream) {
@@ -624,10 +799,9 @@ int ofx_expand_mask(const uint8_t* mask, const uint8_t* image_bgr, uint8_t* out,
     (void)scratch;
     OFX_REQUIRE(mask && image_bgr && out && B > 0 && H > 0 && W > 0, OFX_EINVAL);
     OFX_REQUIRE(ksize >= 1 && ksize <= kMaxK && (ksize & 1), OFX_EINVAL);
-    DilateArgs a{};
-    a.in_u8 = image_bgr; a.or_mask = mask; a.out = out; a.H = H; a.W = W; a.edge_thres = edge_thres;
-    a.el = make_ellipse(ksize);
-    return launch_dilate<SRC_EDGES>(a, B, (hipStream_t)stream, "expand_mask");
+    const Ellipse el = make_ellipse(ksize);
+    return ofx_mask_bits_launch(SRC_EDGES, nullptr, nullptr, image_bgr, mask, out, B, H, W, 0.f, edge_thres, el.r, el.hw,
+                                "expand_mask", (hipStream_t)stream);
 }
 
 int ofx_travel_distance(const float* flow, const float* conf, float* out, int B, int H, int W, float conf_floor,

@@ -257,6 +257,29 @@ def test_warp_float_modes_against_oracle_and_grid_sample(cuda, mode):
     assert d.max() <= 1 and (d > 0).mean() < 1e-3
 
 
+@pytest.mark.parametrize("H,W", [(45, 37), (32, 64), (9, 4), (50, 130)])
+def test_warp_u8_rgb_fast_path_matches_oracle(cuda, H, W):
+    """uint8 x 3 channels takes the 4-pixels-per-thread kernel: borders, ragged widths, far flows."""
+    ops = _ops()
+    frame, flow = _warp_inputs(16, H=H, W=W, C=3, amp=5.0)
+    flow[-1, -1] = (0.25, 0.25)            # bottom-right pixel: taps straddle the end of the frame buffer
+    flow[-1, -2] = (0.75, 0.5)
+    flow[0, 1] = (-1.5, -0.5)              # top-left border
+    for mode in ("bilinear", "cv2_cubic"):
+        ref = WO.warp_frame(frame, flow, mode=mode)
+        out = ops.warp(torch.from_numpy(frame).cuda(), torch.from_numpy(flow).cuda(), mode=mode).cpu().numpy()
+        if mode == "cv2_cubic":
+            assert not _diff(out, ref), _diff(out, ref)
+        else:
+            d = np.abs(out.astype(int) - ref.astype(int))
+            assert d.max() <= 1 and (d > 0).mean() < 2e-3, (d.max(), (d > 0).mean())
+    # the generic (4-channel) kernel and the fast path agree on the shared channels
+    f4 = np.concatenate([frame, frame[:, :, :1]], -1)
+    out4 = ops.warp(torch.from_numpy(f4).cuda(), torch.from_numpy(flow).cuda(), mode="bilinear").cpu().numpy()
+    out3 = ops.warp(torch.from_numpy(frame).cuda(), torch.from_numpy(flow).cuda(), mode="bilinear").cpu().numpy()
+    assert np.array_equal(out4[:, :, :3], out3)
+
+
 def test_warp_batched_shared_keyframe(cuda):
     ops = _ops()
     frame, flow = _warp_inputs(14)

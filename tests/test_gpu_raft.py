@@ -64,7 +64,9 @@ def test_stage_parity_one_iteration(engine, raft_sd):
         p = engine.buffer(f"pyr{l}").cpu()
         assert (p - tr["pyramid"][l].reshape(-1)).abs().max().item() < 5e-4, l
     hx = engine.buffer("hx").cpu().reshape(B * h * w, 384)
-    assert (hx[:, 128:256] - tr["inp"].permute(0, 2, 3, 1).reshape(-1, 128)).abs().max().item() < 2e-4
+    # hx row layout: [h(128) | motion(126) flow(2) | inp(128)]
+    assert (hx[:, 256:384] - tr["inp"].permute(0, 2, 3, 1).reshape(-1, 128)).abs().max().item() < 2e-4
+    assert (hx[:, 254:256] - lo_ref.reshape(-1, 2)).abs().max().item() < 2e-4     # flow slot = coords1 - coords0
     assert (hx[:, :128] - tr["net_it0"].permute(0, 2, 3, 1).reshape(-1, 128)).abs().max().item() < 5e-4
     corr = engine.buffer("corr").cpu()
     assert (corr - nhwc(tr["corr_it0"])).abs().max().item() < 5e-4
