@@ -204,7 +204,9 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    # OFX_BENCH_FORCE_DIST=1 exercises the RCCL code path (init, broadcast, barrier, all-reduce) on one rank
+    use_dist = world > 1 or (os.environ.get("OFX_BENCH_FORCE_DIST") == "1" and "MASTER_PORT" in os.environ)
+    if use_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
@@ -212,7 +214,7 @@ def main():
     else:
         dist = None
         torch.cuda.set_device(0)
-    dev = torch.device("cuda", local_rank if world > 1 else 0)
+    dev = torch.device("cuda", local_rank if use_dist else 0)
     n_gpus = world if world > 1 else 1
     if args.gpus != n_gpus and rank == 0:
         print(f"# note: --gpus {args.gpus} but WORLD_SIZE={world}; using {n_gpus}", file=sys.stderr)

@@ -65,7 +65,6 @@ struct ConvK {
 #define OFX_SCHED 2
 #endif
 constexpr int kBK = 32;
-constexpr int kLDK = 36;   // LDS row stride in floats: 144 B keeps b128 fragment reads conflict-free
 
 __device__ __forceinline__ float apply_act_rt(float v, int act) {
     switch (act) {
@@ -76,12 +75,16 @@ __device__ __forceinline__ float apply_act_rt(float v, int act) {
     }
 }
 
-template <int BM, int BN, int WM, int WN, int EPI, bool NORM>
+template <int BM, int BN, int WM, int WN, int EPI, bool NORM, int BK>
 __global__ __launch_bounds__(256) void igemm_kernel(const ConvK p) {
     constexpr int TM = WM / 32, TN = WN / 32;
     constexpr int WAVES_N = BN / WN;
-    constexpr int A_PER = BM / 32, B_PER = BN / 32;
-    constexpr int STAGE = (BM + BN) * kLDK;
+    constexpr int LDK = BK + 4;               // LDS row stride in floats (144 B / 80 B): conflict-free b128 fragment reads
+    constexpr int QPR = BK / 4;               // float4 slots per staged row
+    constexpr int RPG = 256 / QPR;            // rows staged per pass of the 256 threads
+    constexpr int A_PER = BM / RPG, B_PER = BN / RPG;
+    static_assert(A_PER >= 1 && B_PER >= 1, "tile too small for this BK");
+    constexpr int STAGE = (BM + BN) * LDK;
     static_assert((BM / WM) * (BN / WN) == 4, "4 waves per workgroup");
     __shared__ __attribute__((aligned(16))) float smem[2 * STAGE];
 
@@ -117,13 +120,13 @@ __global__ __launch_bounds__(256) void igemm_kernel(const ConvK p) {
     constexpr int kOOB = 0x7FFFFFF0;
 
     // ---- per-thread gather coordinates for the A (im2col) tile
-    const int kq = tid & 7;    // float4 slot inside the 32-wide k chunk
-    const int r0 = tid >> 3;   // 0..31: row inside each 32-row group
+    const int kq = tid % QPR;   // float4 slot inside the BK-wide k chunk
+    const int r0 = tid / QPR;   // row inside each RPG-row group
     const int HWo = p.Hout * p.Wout;
     int apix[A_PER], a_iy0[A_PER], a_ix0[A_PER], a_b[NORM ? A_PER : 1];
 #pragma unroll
     for (int i = 0; i < A_PER; ++i) {
-        const int m = min(m0 + r0 + 32 * i, p.M - 1);   // rows past M are computed but never stored
+        const int m = min(m0 + r0 + RPG * i, p.M - 1);   // rows past M are computed but never stored
         const int b = m / HWo;
         const int rem = m - b * HWo;
         const int oy = rem / p.Wout;
@@ -135,7 +138,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const ConvK p) {
     }
     int browb[B_PER];
 #pragma unroll
-    for (int i = 0; i < B_PER; ++i) browb[i] = (n0 + r0 + 32 * i) * (p.Kpad * 4) + kq * 16;   // rows past Cout fall off the extent
+    for (int i = 0; i < B_PER; ++i) browb[i] = (n0 + r0 + RPG * i) * (p.Kpad * 4) + kq * 16;   // rows past Cout fall off the extent
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -145,7 +148,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const ConvK p) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-    const int nk = p.Kpad / kBK;
+    const int nk = p.Kpad / BK;
     const int frag_row = lane & 31;
     const int frag_k = (lane >> 5) * 4;
 
@@ -162,7 +165,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const ConvK p) {
     auto offsets = [&](int chunk) __attribute__((always_inline)) {
         // byte offsets of chunk `chunk`: pure VALU, no memory access -> the scheduler interleaves it
         // with the MFMA block that follows it in the steady-state loop body
-        const int k0 = chunk * kBK;
+        const int k0 = chunk * BK;
         const int k = k0 + kq * 4;
         const int tap = (int)__umulhi((unsigned)k, p.magic_cin);
         const int cch = k - tap * p.cin;
@@ -220,7 +223,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const ConvK p) {
     };
 
     auto commit = [&](float* As) __attribute__((always_inline)) {
-        float* Bs = As + BM * kLDK;
+        float* Bs = As + BM * LDK;
 #pragma unroll
         for (int i = 0; i < A_PER; ++i) {
             float4 v = ra[i];
@@ -231,10 +234,10 @@ __global__ __launch_bounds__(256) void igemm_kernel(const ConvK p) {
                 v.w = fmaxf((v.w - rmu[i].w) * rrs[i].w, 0.f);
                 if (!((okbits >> i) & 1u)) v = make_float4(0.f, 0.f, 0.f, 0.f);
             }
-            *reinterpret_cast<float4*>(&As[(r0 + 32 * i) * kLDK + kq * 4]) = v;
+            *reinterpret_cast<float4*>(&As[(r0 + RPG * i) * LDK + kq * 4]) = v;
         }
 #define OFX_B_COMMIT(i) \
-    if constexpr (B_PER > i) *reinterpret_cast<float4*>(&Bs[(r0 + 32 * i) * kLDK + kq * 4]) = rb##i;
+    if constexpr (B_PER > i) *reinterpret_cast<float4*>(&Bs[(r0 + RPG * i) * LDK + kq * 4]) = rb##i;
         OFX_B_COMMIT(0) OFX_B_COMMIT(1) OFX_B_COMMIT(2) OFX_B_COMMIT(3)
 #undef OFX_B_COMMIT
     };
@@ -252,16 +255,16 @@ __global__ __launch_bounds__(256) void igemm_kernel(const ConvK p) {
     for (int kt = 0; kt < nk; ++kt) {
         offsets(min(kt + 2, nk - 1));
         const float* As = smem + (kt & 1) * STAGE;
-        const float* Bs = As + BM * kLDK;
+        const float* Bs = As + BM * LDK;
 #pragma unroll
-        for (int ks = 0; ks < kBK / 8; ++ks) {
+        for (int ks = 0; ks < BK / 8; ++ks) {
             float4 fa[TM], fb[TN];
 #pragma unroll
             for (int i = 0; i < TM; ++i)
-                fa[i] = *reinterpret_cast<const float4*>(&As[(wm * WM + i * 32 + frag_row) * kLDK + ks * 8 + frag_k]);
+                fa[i] = *reinterpret_cast<const float4*>(&As[(wm * WM + i * 32 + frag_row) * LDK + ks * 8 + frag_k]);
 #pragma unroll
             for (int j = 0; j < TN; ++j)
-                fb[j] = *reinterpret_cast<const float4*>(&Bs[(wn * WN + j * 32 + frag_row) * kLDK + ks * 8 + frag_k]);
+                fb[j] = *reinterpret_cast<const float4*>(&Bs[(wn * WN + j * 32 + frag_row) * LDK + ks * 8 + frag_k]);
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -332,18 +335,18 @@ __global__ __launch_bounds__(256) void igemm_kernel(const ConvK p) {
     }
 }
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, int BK>
 int launch_tile(const ConvK& k, int epi, bool norm, int nz, hipStream_t s) {
     dim3 grid((unsigned)(k.mtiles * k.ntiles), (unsigned)nz, 1);
     dim3 block(256, 1, 1);
     switch (epi) {
         case OFX_EPI_PLAIN:
-            if (norm) hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, OFX_EPI_PLAIN, true>), grid, block, 0, s, k);
-            else hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, OFX_EPI_PLAIN, false>), grid, block, 0, s, k);
+            if (norm) hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, OFX_EPI_PLAIN, true, BK>), grid, block, 0, s, k);
+            else hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, OFX_EPI_PLAIN, false, BK>), grid, block, 0, s, k);
             break;
-        case OFX_EPI_GRU_ZR: hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, OFX_EPI_GRU_ZR, false>), grid, block, 0, s, k); break;
-        case OFX_EPI_GRU_Q: hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, OFX_EPI_GRU_Q, false>), grid, block, 0, s, k); break;
-        case OFX_EPI_FLOW: hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, OFX_EPI_FLOW, false>), grid, block, 0, s, k); break;
+        case OFX_EPI_GRU_ZR: hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, OFX_EPI_GRU_ZR, false, BK>), grid, block, 0, s, k); break;
+        case OFX_EPI_GRU_Q: hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, OFX_EPI_GRU_Q, false, BK>), grid, block, 0, s, k); break;
+        case OFX_EPI_FLOW: hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, OFX_EPI_FLOW, false, BK>), grid, block, 0, s, k); break;
         default: return OFX_EINVAL;
     }
     return ofx_launch_status();
@@ -422,7 +425,7 @@ extern "C" int ofx_conv2d_alpha(const ofx_conv_desc* d, float alpha, void* strea
     // ---- tile selection
     int bm, bn;
     if (d->tile) {
-        bm = d->tile / 1000;
+        bm = (d->tile % 1000000) / 1000;
         bn = d->tile % 1000;
     } else {
         auto waste = [&](int t) { return (double)(((d->Cout + t - 1) / t) * t) / d->Cout; };
@@ -446,10 +449,17 @@ extern "C" int ofx_conv2d_alpha(const ofx_conv_desc* d, float alpha, void* strea
                        : d->epi == OFX_EPI_FLOW   ? "igemm_conv_flow"
                                                   : "igemm_conv";
     OfxProfScope prof(pname, s);
-    if (bm == 128 && bn == 128) return launch_tile<128, 128, 64, 64>(k, d->epi, norm, nz, s);
-    if (bm == 128 && bn == 64) return launch_tile<128, 64, 64, 32>(k, d->epi, norm, nz, s);
-    if (bm == 128 && bn == 32) return launch_tile<128, 32, 32, 32>(k, d->epi, norm, nz, s);
-    if (bm == 64 && bn == 64) return launch_tile<64, 64, 32, 32>(k, d->epi, norm, nz, s);
+    // BK = 16 keeps LDS at 41 KB and registers under 168 for the 128x128 tile -> 3 workgroups per CU; the
+    // extra resident wave per SIMD hides the commit/barrier/issue phases better than a longer chunk does
+    // (measured +4..10 % on every shape).  tile = BK*1e6 + BM*1e3 + BN overrides.
+    const int bk = d->tile >= 1000000 ? d->tile / 1000000 : (bn == 32 ? 32 : 16);
+    if (bm == 128 && bn == 128 && bk == 16) return launch_tile<128, 128, 64, 64, 16>(k, d->epi, norm, nz, s);
+    if (bm == 128 && bn == 64 && bk == 16) return launch_tile<128, 64, 64, 32, 16>(k, d->epi, norm, nz, s);
+    if (bm == 128 && bn == 128) return launch_tile<128, 128, 64, 64, 32>(k, d->epi, norm, nz, s);
+    if (bm == 128 && bn == 64) return launch_tile<128, 64, 64, 32, 32>(k, d->epi, norm, nz, s);
+    if (bm == 128 && bn == 32) return launch_tile<128, 32, 32, 32, 32>(k, d->epi, norm, nz, s);
+    if (bm == 64 && bn == 64 && bk == 16) return launch_tile<64, 64, 32, 32, 16>(k, d->epi, norm, nz, s);
+    if (bm == 64 && bn == 64) return launch_tile<64, 64, 32, 32, 32>(k, d->epi, norm, nz, s);
     return OFX_EINVAL;
 }
 

@@ -14,36 +14,40 @@ SHAPES = [  # name, B, H, W, Cin, Cout, kh, kw, stride, tile
     ("enc 3x3 64->64 @1/2", 16, 384, 256, 64, 64, 3, 3, 1, 0),
     ("enc 3x3 96->96 @1/4", 16, 192, 128, 96, 96, 3, 3, 1, 0),
 ]
+TILES = [0, 128128, 16128128, 128064, 16128064]
+
+
 def run(libpath):
     lib = C.CDLL(libpath)
     lib.ofx_conv2d.restype = C.c_int
     lib.ofx_conv2d.argtypes = [C.POINTER(_lib.ConvDesc), C.c_void_p]
     print("==", os.path.basename(libpath))
-    for name, B, H, W, ci, co, kh, kw, st, tile in SHAPES:
-        x = torch.randn((B, H, W, ci), device="cuda")
-        K = kh * kw * ci
-        Kp = (K + 31) // 32 * 32
-        w = torch.randn((co, Kp), device="cuda") * 0.02
-        out = torch.empty((B, H // st, W // st, co), device="cuda")
-        d = _lib.ConvDesc()
-        d.in0, d.ld0, d.c0 = x.data_ptr(), ci, ci
-        d.w = w.data_ptr(); d.out = out.data_ptr(); d.ldo = co
-        d.B, d.Hin, d.Win, d.Hout, d.Wout, d.Cout = B, H, W, H // st, W // st, co
-        d.KH, d.KW, d.stride, d.padH, d.padW = kh, kw, st, kh // 2, kw // 2
-        d.act, d.epi, d.tile = 1, 0, tile
-        s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-        for _ in range(3):
-            assert lib.ofx_conv2d(C.byref(d), s) == 0
-        torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        n = 10
-        e0.record()
-        for _ in range(n):
-            lib.ofx_conv2d(C.byref(d), s)
-        e1.record(); torch.cuda.synchronize()
-        ms = e0.elapsed_time(e1) / n
-        fl = 2.0 * B * (H // st) * (W // st) * co * K
-        print(f"  {name:<24} {ms:8.3f} ms  {fl / ms / 1e9:7.1f} TFLOP/s")
+    for name, B, H, W, ci, co, kh, kw, st, _ in SHAPES:
+      for tile in TILES:
+            x = torch.randn((B, H, W, ci), device="cuda")
+            K = kh * kw * ci
+            Kp = (K + 31) // 32 * 32
+            w = torch.randn((co, Kp), device="cuda") * 0.02
+            out = torch.empty((B, H // st, W // st, co), device="cuda")
+            d = _lib.ConvDesc()
+            d.in0, d.ld0, d.c0 = x.data_ptr(), ci, ci
+            d.w = w.data_ptr(); d.out = out.data_ptr(); d.ldo = co
+            d.B, d.Hin, d.Win, d.Hout, d.Wout, d.Cout = B, H, W, H // st, W // st, co
+            d.KH, d.KW, d.stride, d.padH, d.padW = kh, kw, st, kh // 2, kw // 2
+            d.act, d.epi, d.tile = 1, 0, tile
+            s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+            for _ in range(3):
+                assert lib.ofx_conv2d(C.byref(d), s) == 0
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            n = 10
+            e0.record()
+            for _ in range(n):
+                lib.ofx_conv2d(C.byref(d), s)
+            e1.record(); torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / n
+            fl = 2.0 * B * (H // st) * (W // st) * co * K
+            print(f"  {name:<24} tile {tile:>9} {ms:8.3f} ms  {fl / ms / 1e9:7.1f} TFLOP/s")
 if __name__ == "__main__":
     libs = sys.argv[1:] or [_lib.LIB_PATH]
     for l in libs:
