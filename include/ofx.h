@@ -202,6 +202,14 @@ size_t ofx_raft_workspace_bytes(const ofx_raft* r, int B, int H, int W);
 int ofx_raft_forward(ofx_raft* r, const uint8_t* image1, const uint8_t* image2, int B, int H, int W,
                      int iters, int flags, float* flow_up, float* flow_low, void* workspace,
                      size_t workspace_bytes, void* stream);
+/* Indexed pairs ("next" row f1, KeyframeConv / calculate_pairwise, ofgen_keyframe_inpaint.py:627-668):
+ * n_images unique uint8 frames [n,H,W,3] on the device and B pairs (idx1[b], idx2[b]) given as HOST int
+ * arrays; flow b is defined on image idx1[b] and points into image idx2[b].  Every image is encoded once
+ * (feature + context network), so N*(N-1) ordered pairs cost N encoder passes instead of 3*N*(N-1). */
+size_t ofx_raft_workspace_bytes_pairs(const ofx_raft* r, int n_images, int B, int H, int W);
+int ofx_raft_forward_pairs(ofx_raft* r, const uint8_t* images, int n_images, const int* idx1,
+                           const int* idx2, int B, int H, int W, int iters, int flags, float* flow_up,
+                           float* flow_low, void* workspace, size_t workspace_bytes, void* stream);
 /* debug / stage-parity access to the buffers of the last forward: returns a device pointer and
  * element count for a named intermediate ("fmap1","fmap2","hx","corr","pyr0".."pyr3","mask",...) */
 int ofx_raft_buffer(const ofx_raft* r, const char* name, void** ptr, size_t* nfloats);

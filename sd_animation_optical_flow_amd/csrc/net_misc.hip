@@ -192,6 +192,29 @@ int ofx_init_state(float* coords1, float* flow4, float* hx, int ldh, int flow_of
     return ofx_launch_status();
 }
 
+// hx[b, :, 0:half] = ctx[idx[b], :, 0:half], hx[b, :, off2:off2+half] = ctx[idx[b], :, half:2*half]
+// (per-pair gather of the per-image context features in the indexed-pairs forward)
+__global__ __launch_bounds__(256) void ctx_gather_kernel(const float* __restrict__ ctx, const int* __restrict__ idx,
+                                                         float* __restrict__ hx, int ldh, int off2, int half, long N, long total4) {
+    const int q = half / 4;   // float4 per half row
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
+        const int c4 = (int)(i % (2 * q));
+        const long pp = i / (2 * q);          // b*N + p
+        const long b = pp / N, p = pp - b * N;
+        const float4 v = reinterpret_cast<const float4*>(ctx + ((long)idx[b] * N + p) * (2 * half))[c4];
+        float* dst = hx + pp * ldh + (c4 < q ? c4 * 4 : off2 + (c4 - q) * 4);
+        *reinterpret_cast<float4*>(dst) = v;
+    }
+}
+
+int ofx_ctx_gather(const float* ctx, const int* idx_dev, float* hx, int ldh, int off2, int half, int B, long N, hipStream_t s) {
+    const long total4 = (long)B * N * (2 * half / 4);
+    OfxProfScope prof("ctx_gather", s);
+    hipLaunchKernelGGL(ctx_gather_kernel, dim3((unsigned)std::min<long>((total4 + 255) / 256, 8192)), dim3(256), 0, s, ctx, idx_dev,
+                       hx, ldh, off2, half, N, total4);
+    return ofx_launch_status();
+}
+
 int ofx_coords_to_flow(const float* coords1, float* flow, int B, int h, int w, hipStream_t s) {
     const long M = (long)B * h * w;
     OfxProfScope prof("coords_to_flow", s);

@@ -360,18 +360,22 @@ static int run_encoder(ofx_raft* r, const std::string& enc, bool bn, const uint8
 struct RaftWs {
     EncBufs eb;
     float *fmap1, *fmap2, *f2l[LEVELS];
+    float* ctx;       // indexed-pairs mode: per-image context features [n][N][256] (tanh | relu halves)
+    int* idx_dev;     // indexed-pairs mode: image1 index per pair
     float* pyr[LEVELS];
     float *hx, *gadd, *coords1, *flow4, *corr, *c1, *corflo, *f1, *z, *rh, *mask;
     size_t bytes;
 };
 
-static RaftWs carve(void* base, size_t cap, int B, int H, int W, int flags) {
+// n_images > 0 selects the indexed-pairs layout: one feature map + one context map per unique image
+static RaftWs carve(void* base, size_t cap, int B, int H, int W, int flags, int n_images = 0) {
     RaftWs w{};
     Carver c(base, cap);
     const int h = H / 8, wd = W / 8;
     const long N = (long)h * wd;
     const long M = (long)B * N;
-    const int nch = ENC_CHUNK < 2 * B ? ENC_CHUNK : 2 * B;
+    const int most = n_images > 0 ? n_images : 2 * B;
+    const int nch = ENC_CHUNK < most ? ENC_CHUNK : most;
     const long half = (long)(H / 2) * (W / 2) * 64;
     w.eb.x0 = c.take((size_t)nch * H * W * 4);
     w.eb.X = c.take((size_t)nch * half);
@@ -381,9 +385,15 @@ static RaftWs carve(void* base, size_t cap, int B, int H, int W, int flags) {
     w.eb.R3 = c.take((size_t)nch * (H / 4) * (W / 4) * 96);
     w.eb.stats = c.take((size_t)6 * ENC_CHUNK * 128);
     w.eb.scratch = c.take((size_t)ENC_CHUNK * 64 * 128 * 2 * 2);   // doubles: chunk x slices x C x {sum, sumsq}
-    const long n1 = (flags & OFX_RAFT_SHARED_IMG1) ? 1 : B, n2 = (flags & OFX_RAFT_SHARED_IMG2) ? 1 : B;
+    long n1 = (flags & OFX_RAFT_SHARED_IMG1) ? 1 : B, n2 = (flags & OFX_RAFT_SHARED_IMG2) ? 1 : B;
+    if (n_images > 0) {
+        n1 = n_images;
+        n2 = 0;
+        w.ctx = c.take((size_t)n_images * N * (HD + CD));
+        w.idx_dev = (int*)c.take((size_t)B);
+    }
     w.fmap1 = c.take((size_t)n1 * N * FD);
-    w.fmap2 = c.take((size_t)n2 * N * FD);
+    w.fmap2 = n2 ? c.take((size_t)n2 * N * FD) : w.fmap1;
     if (flags & OFX_RAFT_ALT_CORR) {
         w.f2l[0] = w.fmap2;
         for (int l = 1; l < LEVELS; ++l) w.f2l[l] = c.take((size_t)n2 * (h >> l) * (wd >> l) * FD);
@@ -403,6 +413,78 @@ static RaftWs carve(void* base, size_t cap, int B, int H, int W, int flags) {
     w.mask = c.take((size_t)M * 576);
     w.bytes = c.off;
     return w;
+}
+
+// everything after the feature / context encoders and the correlation volume: state init, the loop-invariant
+// GRU terms, `iters` refinement iterations, mask head, convex upsample
+static int run_recurrence(ofx_raft* r, const RaftWs& ws, int B, int h, int w, int iters, bool alt, bool shared,
+                          float* flow_up, float* flow_low, hipStream_t s) {
+    const long N = (long)h * w;
+    const bool sh1 = shared, sh2 = shared;
+    int st = 0;
+    st = ofx_init_state(ws.coords1, ws.flow4, ws.hx, HX_LD, FLOW_OFF, B, h, w, s);
+    if (st) return st;
+    {   // loop-invariant GRU terms: conv(W[:, inp], inp) + bias for z|r and q of both passes
+        Launcher G{s};
+        const char* names[4] = {"gru.zr1.inp", "gru.q1.inp", "gru.zr2.inp", "gru.q2.inp"};
+        const int offs[4] = {0, 2 * HD, 3 * HD, 5 * HD};
+        for (int i = 0; i < 4; ++i)
+            G.conv(r->convs[names[i]], ws.hx + INP_OFF, HX_LD, CD, nullptr, 0, 0, ws.gadd + offs[i], GADD_LD, B, h, w, 1,
+                   OFX_ACT_NONE);
+        if (G.st) return G.st;
+    }
+
+    Launcher L{s};
+    auto C = [&](const char* k) -> const ConvW& { return r->convs[k]; };
+    const float* pyr_c[LEVELS] = {ws.pyr[0], ws.pyr[1], ws.pyr[2], ws.pyr[3]};
+    const int rd2 = (2 * RADIUS + 1) * (2 * RADIUS + 1);
+    for (int it = 0; it < iters && !L.st; ++it) {
+        // correlation features at the current estimate
+        if (!alt) {
+            L.st = ofx_corr_lookup(pyr_c, ws.coords1, ws.corr, CORR_CH, B, h, w, LEVELS, RADIUS, s);
+        } else {
+            for (int l = 0; l < LEVELS && !L.st; ++l) {
+                if (sh1 || sh2) { L.st = OFX_EINVAL; break; }   // alt-corr path: per-pair feature maps only
+                L.st = ofx_local_corr_launch(ws.fmap1, ws.f2l[l], ws.coords1, ws.corr + (long)l * rd2, N * CORR_CH, 0, 1,
+                                             CORR_CH, B, h, w, h >> l, w >> l, FD, 1, RADIUS, 1.0f / std::sqrt((float)FD),
+                                             1.0f / (float)(1 << l), s);
+            }
+        }
+        // motion encoder (update.py:88-97)
+        L.conv(C("convc1"), ws.corr, CORR_CH, CORR_CH, nullptr, 0, 0, ws.c1, 256, B, h, w, 1, OFX_ACT_RELU);
+        L.conv(C("convc2"), ws.c1, 256, 256, nullptr, 0, 0, ws.corflo, 256, B, h, w, 1, OFX_ACT_RELU);
+        L.conv(C("convf1"), ws.flow4, 4, 4, nullptr, 0, 0, ws.f1, 128, B, h, w, 1, OFX_ACT_RELU);
+        L.conv(C("convf2"), ws.f1, 128, 128, nullptr, 0, 0, ws.corflo + 192, 256, B, h, w, 1, OFX_ACT_RELU);
+        L.conv(C("conv"), ws.corflo, 256, 256, nullptr, 0, 0, ws.hx + MOT_OFF, HX_LD, B, h, w, 1, OFX_ACT_RELU);
+        // SepConvGRU (update.py:44-60): horizontal then vertical pass
+        for (int pass = 1; pass <= 2; ++pass) {
+            const char* zr = pass == 1 ? "gru.zr1" : "gru.zr2";
+            const char* q = pass == 1 ? "gru.q1" : "gru.q2";
+            const float* g = ws.gadd + (pass - 1) * (3 * HD);
+            L.addend = g; L.ldadd = GADD_LD;
+            L.conv(C(zr), ws.hx, HX_LD, 2 * HD, nullptr, 0, 0, nullptr, 0, B, h, w, 1, OFX_ACT_NONE, OFX_EPI_GRU_ZR, nullptr, 0,
+                   nullptr, nullptr, ws.z, ws.rh, ws.hx, HX_LD);
+            L.addend = g + 2 * HD; L.ldadd = GADD_LD;
+            L.conv(C(q), ws.rh, HD, HD, ws.hx + MOT_OFF, HX_LD, 128, nullptr, 0, B, h, w, 1, OFX_ACT_NONE, OFX_EPI_GRU_Q,
+                   nullptr, 0, nullptr, nullptr, ws.z, nullptr, ws.hx, HX_LD);
+        }
+        // flow head (update.py:6-14) + coords1 += delta (raft.py:131) in the epilogue
+        L.conv(C("fh1"), ws.hx, HX_LD, HD, nullptr, 0, 0, ws.c1, 256, B, h, w, 1, OFX_ACT_RELU);
+        L.conv(C("fh2"), ws.c1, 256, 256, nullptr, 0, 0, nullptr, 0, B, h, w, 1, OFX_ACT_NONE, OFX_EPI_FLOW, nullptr, 0,
+               nullptr, nullptr, nullptr, nullptr, ws.hx + FLOW_OFF, HX_LD, ws.coords1, ws.flow4);
+    }
+    // mask head (update.py:122-125,135) on the final hidden state, then convex upsample
+    L.conv(C("mask0"), ws.hx, HX_LD, HD, nullptr, 0, 0, ws.c1, 256, B, h, w, 1, OFX_ACT_RELU);
+    L.conv(C("mask2"), ws.c1, 256, 256, nullptr, 0, 0, ws.mask, 576, B, h, w, 1, OFX_ACT_NONE);
+    if (L.st) return L.st;
+    st = ofx_upsample_flow(ws.coords1, ws.mask, flow_up, B, h, w, s);
+    if (st) return st;
+    if (flow_low) {
+        st = ofx_coords_to_flow(ws.coords1, flow_low, B, h, w, s);
+        if (st) return st;
+    }
+
+    return 0;
 }
 
 extern "C" {
@@ -530,67 +612,8 @@ int ofx_raft_forward(ofx_raft* r, const uint8_t* image1, const uint8_t* image2, 
         if (st) return st;
     }
 
-    st = ofx_init_state(ws.coords1, ws.flow4, ws.hx, HX_LD, FLOW_OFF, B, h, w, s);
+    st = run_recurrence(r, ws, B, h, w, iters, alt, sh1 || sh2, flow_up, flow_low, s);
     if (st) return st;
-    {   // loop-invariant GRU terms: conv(W[:, inp], inp) + bias for z|r and q of both passes
-        Launcher G{s};
-        const char* names[4] = {"gru.zr1.inp", "gru.q1.inp", "gru.zr2.inp", "gru.q2.inp"};
-        const int offs[4] = {0, 2 * HD, 3 * HD, 5 * HD};
-        for (int i = 0; i < 4; ++i)
-            G.conv(r->convs[names[i]], ws.hx + INP_OFF, HX_LD, CD, nullptr, 0, 0, ws.gadd + offs[i], GADD_LD, B, h, w, 1,
-                   OFX_ACT_NONE);
-        if (G.st) return G.st;
-    }
-
-    Launcher L{s};
-    auto C = [&](const char* k) -> const ConvW& { return r->convs[k]; };
-    const float* pyr_c[LEVELS] = {ws.pyr[0], ws.pyr[1], ws.pyr[2], ws.pyr[3]};
-    const int rd2 = (2 * RADIUS + 1) * (2 * RADIUS + 1);
-    for (int it = 0; it < iters && !L.st; ++it) {
-        // correlation features at the current estimate
-        if (!alt) {
-            L.st = ofx_corr_lookup(pyr_c, ws.coords1, ws.corr, CORR_CH, B, h, w, LEVELS, RADIUS, s);
-        } else {
-            for (int l = 0; l < LEVELS && !L.st; ++l) {
-                if (sh1 || sh2) { L.st = OFX_EINVAL; break; }   // alt-corr path: per-pair feature maps only
-                L.st = ofx_local_corr_launch(ws.fmap1, ws.f2l[l], ws.coords1, ws.corr + (long)l * rd2, N * CORR_CH, 0, 1,
-                                             CORR_CH, B, h, w, h >> l, w >> l, FD, 1, RADIUS, 1.0f / std::sqrt((float)FD),
-                                             1.0f / (float)(1 << l), s);
-            }
-        }
-        // motion encoder (update.py:88-97)
-        L.conv(C("convc1"), ws.corr, CORR_CH, CORR_CH, nullptr, 0, 0, ws.c1, 256, B, h, w, 1, OFX_ACT_RELU);
-        L.conv(C("convc2"), ws.c1, 256, 256, nullptr, 0, 0, ws.corflo, 256, B, h, w, 1, OFX_ACT_RELU);
-        L.conv(C("convf1"), ws.flow4, 4, 4, nullptr, 0, 0, ws.f1, 128, B, h, w, 1, OFX_ACT_RELU);
-        L.conv(C("convf2"), ws.f1, 128, 128, nullptr, 0, 0, ws.corflo + 192, 256, B, h, w, 1, OFX_ACT_RELU);
-        L.conv(C("conv"), ws.corflo, 256, 256, nullptr, 0, 0, ws.hx + MOT_OFF, HX_LD, B, h, w, 1, OFX_ACT_RELU);
-        // SepConvGRU (update.py:44-60): horizontal then vertical pass
-        for (int pass = 1; pass <= 2; ++pass) {
-            const char* zr = pass == 1 ? "gru.zr1" : "gru.zr2";
-            const char* q = pass == 1 ? "gru.q1" : "gru.q2";
-            const float* g = ws.gadd + (pass - 1) * (3 * HD);
-            L.addend = g; L.ldadd = GADD_LD;
-            L.conv(C(zr), ws.hx, HX_LD, 2 * HD, nullptr, 0, 0, nullptr, 0, B, h, w, 1, OFX_ACT_NONE, OFX_EPI_GRU_ZR, nullptr, 0,
-                   nullptr, nullptr, ws.z, ws.rh, ws.hx, HX_LD);
-            L.addend = g + 2 * HD; L.ldadd = GADD_LD;
-            L.conv(C(q), ws.rh, HD, HD, ws.hx + MOT_OFF, HX_LD, 128, nullptr, 0, B, h, w, 1, OFX_ACT_NONE, OFX_EPI_GRU_Q,
-                   nullptr, 0, nullptr, nullptr, ws.z, nullptr, ws.hx, HX_LD);
-        }
-        // flow head (update.py:6-14) + coords1 += delta (raft.py:131) in the epilogue
-        L.conv(C("fh1"), ws.hx, HX_LD, HD, nullptr, 0, 0, ws.c1, 256, B, h, w, 1, OFX_ACT_RELU);
-        L.conv(C("fh2"), ws.c1, 256, 256, nullptr, 0, 0, nullptr, 0, B, h, w, 1, OFX_ACT_NONE, OFX_EPI_FLOW, nullptr, 0,
-               nullptr, nullptr, nullptr, nullptr, ws.hx + FLOW_OFF, HX_LD, ws.coords1, ws.flow4);
-    }
-    // mask head (update.py:122-125,135) on the final hidden state, then convex upsample
-    L.conv(C("mask0"), ws.hx, HX_LD, HD, nullptr, 0, 0, ws.c1, 256, B, h, w, 1, OFX_ACT_RELU);
-    L.conv(C("mask2"), ws.c1, 256, 256, nullptr, 0, 0, ws.mask, 576, B, h, w, 1, OFX_ACT_NONE);
-    if (L.st) return L.st;
-    st = ofx_upsample_flow(ws.coords1, ws.mask, flow_up, B, h, w, s);
-    if (st) return st;
-    if (flow_low) {
-        st = ofx_coords_to_flow(ws.coords1, flow_low, B, h, w, s);
-        if (st) return st;
-    }
 
     r->bufs.clear();
     auto reg = [&](const char* k, float* p, size_t nf) { r->bufs[k] = std::make_pair((void*)p, nf); };
@@ -606,6 +629,61 @@ int ofx_raft_forward(ofx_raft* r, const uint8_t* image1, const uint8_t* image2, 
             snprintf(nm, sizeof nm, "pyr%d", l);
             reg(nm, ws.pyr[l], (size_t)M * (h >> l) * (w >> l));
         }
+    return 0;
+}
+
+size_t ofx_raft_workspace_bytes_pairs(const ofx_raft* r, int n_images, int B, int H, int W) {
+    (void)r;
+    if (n_images <= 0 || B <= 0 || H <= 0 || W <= 0 || (H % 8) || (W % 8)) return 0;
+    return carve(nullptr, 0, B, H, W, 0, n_images).bytes;
+}
+
+int ofx_raft_forward_pairs(ofx_raft* r, const uint8_t* images, int n_images, const int* idx1, const int* idx2, int B, int H,
+                           int W, int iters, int flags, float* flow_up, float* flow_low, void* workspace,
+                           size_t workspace_bytes, void* stream) {
+    OFX_REQUIRE(r && images && idx1 && idx2 && flow_up && workspace, OFX_EINVAL);
+    OFX_REQUIRE(n_images > 0 && B > 0 && H >= 64 && W >= 64 && (H % 8) == 0 && (W % 8) == 0 && iters >= 1, OFX_EINVAL);
+    OFX_REQUIRE(!(flags & (OFX_RAFT_ALT_CORR | OFX_RAFT_SHARED_IMG1 | OFX_RAFT_SHARED_IMG2)), OFX_EINVAL);
+    OFX_REQUIRE((((uintptr_t)workspace) & 255u) == 0, OFX_EALIGN);
+    for (int b = 0; b < B; ++b)
+        OFX_REQUIRE(idx1[b] >= 0 && idx1[b] < n_images && idx2[b] >= 0 && idx2[b] < n_images, OFX_EINVAL);
+    RaftWs ws = carve(workspace, workspace_bytes, B, H, W, 0, n_images);
+    OFX_REQUIRE(ws.bytes <= workspace_bytes, OFX_ENOMEM);
+    hipStream_t s = (hipStream_t)stream;
+    const int h = H / 8, w = W / 8;
+    const long N = (long)h * w;
+    const int bgr = (flags & OFX_RAFT_BGR) ? 1 : 0;
+    const long img_bytes = (long)H * W * 3;
+    int st = 0;
+    // every image is encoded ONCE (feature + context), however many pairs it takes part in: a 15-frame
+    // KeyframeConv window has 210 ordered pairs but only 15 images (ofgen_keyframe_inpaint.py:627-668)
+    for (int i0 = 0; i0 < n_images && !st; i0 += ENC_CHUNK) {
+        const int n = std::min(ENC_CHUNK, n_images - i0);
+        st = run_encoder(r, "fnet", false, images + i0 * img_bytes, n, H, W, bgr, ws.eb, ws.fmap1 + (long)i0 * N * FD, FD, false,
+                         0, s);
+        if (!st)
+            st = run_encoder(r, "cnet", true, images + i0 * img_bytes, n, H, W, bgr, ws.eb, ws.ctx + (long)i0 * N * (HD + CD),
+                             HD + CD, true, HD, s);
+    }
+    if (st) return st;
+    OFX_HIP_CHECK(hipMemcpyAsync(ws.idx_dev, idx1, sizeof(int) * B, hipMemcpyHostToDevice, s));
+    st = ofx_ctx_gather(ws.ctx, ws.idx_dev, ws.hx, HX_LD, INP_OFF, HD, B, N, s);
+    if (st) return st;
+    for (int b = 0; b < B && !st; ++b) {   // one N x N correlation GEMM per pair, straight from the shared feature maps
+        ofx_conv_desc d{};
+        d.in0 = ws.fmap1 + (long)idx1[b] * N * FD; d.ld0 = FD; d.c0 = FD;
+        d.w = ws.fmap1 + (long)idx2[b] * N * FD;
+        d.out = ws.pyr[0] + (long)b * N * N; d.ldo = (int)N;
+        d.B = 1; d.Hin = h; d.Win = w; d.Hout = h; d.Wout = w; d.Cout = (int)N;
+        d.KH = 1; d.KW = 1; d.stride = 1;
+        d.act = OFX_ACT_NONE; d.epi = OFX_EPI_PLAIN;
+        st = ofx_conv2d_alpha(&d, 1.0f / std::sqrt((float)FD), s);
+    }
+    if (!st) st = ofx_corr_pool_launch(ws.pyr[0], ws.pyr[1], ws.pyr[2], ws.pyr[3], B, h, w, LEVELS, s);
+    if (st) return st;
+    st = run_recurrence(r, ws, B, h, w, iters, false, false, flow_up, flow_low, s);
+    if (st) return st;
+    r->bufs.clear();
     return 0;
 }
 

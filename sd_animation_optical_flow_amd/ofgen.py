@@ -235,6 +235,21 @@ class PDCNetAux:
 
     def calculate_given_pairs(self, video, to_calculate_pairs: List[Tuple[int, int]], s2i_map: Dict[int, int],
                               t2i_map: Dict[int, int], ret: np.ndarray):
+        if len(to_calculate_pairs) > 1 and hasattr(self.pdcnet_model, "calc_pairs"):
+            # fast path ("next" row f1): every distinct frame is decoded, uploaded and encoded once; the
+            # N*(N-1) ordered pairs of a KeyframeConv window share N feature / context maps
+            ids = sorted({i for p in to_calculate_pairs for i in p})
+            lm = {g: l for l, g in enumerate(ids)}
+            frames = np.stack([np.ascontiguousarray(video.get_raw_frame(i)[:, :, ::-1]) for i in ids])     # RGB
+            flow, conf = self.pdcnet_model.calc_pairs(torch.from_numpy(frames).to(self.device),
+                                                      [(lm[s], lm[t]) for s, t in to_calculate_pairs])
+            flow, conf = flow.cpu().numpy(), conf.cpu().numpy()
+            for i, (s, t) in enumerate(to_calculate_pairs):
+                si, ti = s2i_map[s], t2i_map[t]
+                ret[si, ti, :, :, 0:2] = flow[i]
+                ret[si, ti, :, :, 2] = conf[i]
+                np.save(os.path.join(self.pair_dir, f"{s:05d}-{t:05d}.npy"), ret[si, ti])
+            return
         for pair_batch in chunks(to_calculate_pairs, self.batch_size):
             bs = len(pair_batch)
             inp_source = np.zeros((bs, *video.size_hw, 3), dtype=np.uint8)

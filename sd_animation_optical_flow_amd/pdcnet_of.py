@@ -72,6 +72,35 @@ class PDCNetPlus:
         conf, logc = ops.fb_confidence(flow_t, flow_s, self.sigma)
         return flow_t, conf, logc
 
+    @torch.no_grad()
+    def calc_pairs(self, frames: torch.Tensor, pairs, bgr: bool = False, max_flows: int = 64):
+        """Many (source, target) pairs over a small set of frames (KeyframeConv / calculate_pairwise,
+        ofgen_keyframe_inpaint.py:627-668).  frames: uint8 [n,H,W,3] on the device; pairs: list of (s, t)
+        indices into `frames`.  Returns device tensors (flow f32[P,H,W,2] on t's grid pointing into s,
+        confidence f32[P,H,W]).  Each frame is encoded once per chunk, and the backward flow needed by the
+        confidence of (s, t) is shared with pair (t, s) when both are requested."""
+        pairs = [(int(s), int(t)) for s, t in pairs]
+        frames = self.network.pad_to_8(frames.contiguous())
+        need = {}                                    # directed flow (image1, image2) -> slot
+        for s, t in pairs:
+            need.setdefault((t, s), len(need))       # flow on t's grid into s
+            need.setdefault((s, t), len(need))       # its backward companion
+        keys = list(need.keys())
+        flows = [None] * len(keys)
+        for c0 in range(0, len(keys), max_flows):
+            chunk = keys[c0:c0 + max_flows]
+            used = sorted({i for k in chunk for i in k})
+            remap = {g: l for l, g in enumerate(used)}
+            sub = frames[torch.tensor(used, device=frames.device)]
+            out = self.network.forward_pairs(sub, [remap[a] for a, _ in chunk], [remap[b] for _, b in chunk],
+                                             iters=self.iters, bgr=bgr)
+            for j in range(len(chunk)):
+                flows[c0 + j] = out[j]
+        fw = torch.stack([flows[need[(t, s)]] for s, t in pairs])
+        bw = torch.stack([flows[need[(s, t)]] for s, t in pairs])
+        conf, _ = ops.fb_confidence(fw.contiguous(), bw.contiguous(), self.sigma)
+        return fw, conf
+
     # ---- reference-compatible host API ---------------------------------------------------------
     @torch.no_grad()
     def calc(self, frame1: np.ndarray, frame2: np.ndarray):

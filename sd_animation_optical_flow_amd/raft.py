@@ -120,6 +120,36 @@ class RaftEngine:
                                           C.c_void_p(ws.data_ptr()), ws.numel(), stream), "ofx_raft_forward")
         return (flow_up, flow_low) if want_low else flow_up
 
+    @torch.no_grad()
+    def forward_pairs(self, images: torch.Tensor, idx1, idx2, iters: int = 20, bgr: bool = False) -> torch.Tensor:
+        """images: uint8 [n,H,W,3] on the device (H, W multiples of 8); pair b = (idx1[b], idx2[b]):
+        flow b lives on image idx1[b] and points into image idx2[b].  Every image is encoded once however
+        many pairs use it (KeyframeConv's N x N sweep).  Returns f32 [B,H,W,2] on the device."""
+        if not images.is_cuda or images.dtype != torch.uint8 or images.dim() != 4 or images.shape[3] != 3:
+            raise RuntimeError("images must be a CUDA uint8 tensor [n,H,W,3]")
+        imgs = images.contiguous()
+        n, H, W, _ = imgs.shape
+        if H % 8 or W % 8:
+            raise RuntimeError("forward_pairs needs H and W to be multiples of 8 (pad the frames first)")
+        B = len(idx1)
+        if B == 0 or len(idx2) != B:
+            raise RuntimeError("idx1 / idx2 must be non-empty and of equal length")
+        a1 = (C.c_int * B)(*[int(i) for i in idx1])
+        a2 = (C.c_int * B)(*[int(i) for i in idx2])
+        L = _lib.lib()
+        need = L.ofx_raft_workspace_bytes_pairs(self._h, n, B, H, W)
+        if need == 0:
+            raise RuntimeError(f"unsupported shape n={n} B={B} H={H} W={W}")
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = None
+            self._ws = torch.empty((need,), dtype=torch.uint8, device=self.device)
+        flow_up = torch.empty((B, H, W, 2), dtype=torch.float32, device=self.device)
+        stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        check(L.ofx_raft_forward_pairs(self._h, C.c_void_p(imgs.data_ptr()), n, a1, a2, B, H, W, int(iters),
+                                       FLAG_BGR if bgr else 0, C.c_void_p(flow_up.data_ptr()), None,
+                                       C.c_void_p(self._ws.data_ptr()), self._ws.numel(), stream), "ofx_raft_forward_pairs")
+        return flow_up
+
     def buffer(self, name: str) -> torch.Tensor:
         """Copy of a named intermediate of the last forward (flat f32) -- for stage-level parity tests."""
         p, n = C.c_void_p(), C.c_size_t()

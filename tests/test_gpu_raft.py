@@ -108,6 +108,21 @@ def test_alternate_corr_engine_path(engine, raft_sd):
     assert _epe(up.cpu(), up_ref) < 1e-3
 
 
+def test_forward_pairs_encodes_each_image_once(engine, raft_sd):
+    """Indexed pairs (KeyframeConv's N x N sweep): same flows as the pair-by-pair forward and the oracle."""
+    H, W = 128, 160
+    key, frames = _frames(7, 3, H, W)
+    imgs = torch.cat([key[None], frames])                    # 4 distinct images
+    idx1, idx2 = [1, 2, 3, 0, 2, 3], [0, 0, 1, 3, 2, 2]      # includes an identity pair and both directions
+    out = engine.forward_pairs(imgs.cuda(), idx1, idx2, iters=8)
+    ref = engine.forward(imgs[idx1].contiguous().cuda(), imgs[idx2].contiguous().cuda(), iters=8)
+    assert (out - ref).abs().max().item() < 1e-4
+    _, up_ref = _oracle_flow(raft_sd, imgs[idx1], imgs[idx2], 8)
+    assert _epe(out.cpu(), up_ref) < 1e-3
+    with pytest.raises(RuntimeError):
+        engine.forward_pairs(imgs.cuda(), [0, 9], [1, 1])    # index out of range -> OFX_EINVAL
+
+
 def test_non_multiple_of_8_is_padded_like_input_padder(engine, raft_sd):
     H, W = 100, 90
     key, frames = _frames(5, 1, H, W)
