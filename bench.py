@@ -320,6 +320,19 @@ def main():
             tfv = work["volume_flops"] * steps / (m * 1e-3) / 1e12
             ks["corr_volume_gemm"]["tflops"] = round(tfv, 2)
             ks["corr_volume_gemm"]["mfma_frac"] = round(tfv / MFMA_F32_PEAK_TFLOPS, 4)
+        # HBM bytes per launch from the committed PMC passes of this same command (rocprofv3 --pmc FETCH_SIZE /
+        # WRITE_SIZE in separate runs; FETCH_SIZE doubled per the gfx950 correction, calibrated on the pooling
+        # kernel: corrected 12.83 GB = its exact algorithmic 12.83 GB).  PMC cannot be collected inside this run.
+        tp = os.path.join(ROOT, "profiles", "r01b_pmc_traffic_b64.json")
+        if B == 64 and os.path.exists(tp):
+            tr = json.load(open(tp))
+            if "roofline" in out and "igemm_conv_all" in tr:
+                out["roofline"]["traffic"] = tr["igemm_conv_all"]["hbm_bytes_per_launch_corrected"]
+                out["roofline"]["traffic_source"] = "profiles/r01b_pmc_traffic_b64.json (avg over all igemm launches)"
+            for label, key in (("corr_lookup", "corr_lookup"), ("corr_pyramid_pool", "pyramid_pool"), ("upsample_flow", "upsample"),
+                               ("warp", "warp"), ("mask", "mask")):
+                if label in ks and key in tr:
+                    ks[label]["traffic"] = tr[key]["hbm_bytes_per_launch_corrected"]
         out["kernels"] = ks
         tot = sum(v["ms"] for v in kern.values())
         out["kernel_time_share"] = {k: round(v["ms"] / tot, 4) for k, v in sorted(kern.items(), key=lambda kv: -kv[1]["ms"])[:8]}
