@@ -198,6 +198,9 @@ def main():
     ap.add_argument("--no-prof", action="store_true", help="do not bracket launches with HIP events")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-single", action="store_true")
+    ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16x3"],
+                    help="matrix-core arithmetic of the timed run (fp32 = the reference's; bf16x3 = opt-in split-bf16 fast mode)")
+    ap.add_argument("--no-fast", action="store_true", help="skip the secondary bf16x3 measurement")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.cpu_baseline_only:
@@ -227,7 +230,7 @@ def main():
     from sd_animation_optical_flow_amd.weights import random_state_dict
 
     B = args.batch
-    eng = RaftEngine(random_state_dict(0), dev)
+    eng = RaftEngine(random_state_dict(0), dev, precision=args.precision)
     frames, key, key_ai, conf = make_clip(B, H, W, dev, rank)
 
     def step():
@@ -272,7 +275,7 @@ def main():
         "metric": "frame-pairs/sec (flow+warp+mask) at 512x768",
         "value": round(value, 3), "unit": "pairs/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic",
+        "dtype": "f32" if args.precision == "fp32" else "bf16x3 (fp32 operands split into two bf16, fp32 accumulate)", "data": "synthetic",
         "config": {"workload": f"BASELINE configs[2]: {B}-frame 512x768 clip per GPU vs one shared key frame, RAFT {ITERS} iters "
                                f"fp32 + {args.warp_mode} warp + mask(conf<0.95, 7x7); configs[3] sharding at N>1",
                    "frames_per_gpu": B, "H": H, "W": W, "iters": ITERS, "parallelism": f"frame-parallel x{n_gpus}"},
@@ -329,10 +332,10 @@ def main():
             if "roofline" in out and "igemm_conv_all" in tr:
                 out["roofline"]["traffic"] = tr["igemm_conv_all"]["hbm_bytes_per_launch_corrected"]
                 out["roofline"]["traffic_source"] = "profiles/r01b_pmc_traffic_b64.json (avg over all igemm launches)"
-            for label, key in (("corr_lookup", "corr_lookup"), ("corr_pyramid_pool", "pyramid_pool"), ("upsample_flow", "upsample"),
+            for label, tkey in (("corr_lookup", "corr_lookup"), ("corr_pyramid_pool", "pyramid_pool"), ("upsample_flow", "upsample"),
                                ("warp", "warp"), ("mask", "mask")):
-                if label in ks and key in tr:
-                    ks[label]["traffic"] = tr[key]["hbm_bytes_per_launch_corrected"]
+                if label in ks and tkey in tr:
+                    ks[label]["traffic"] = tr[tkey]["hbm_bytes_per_launch_corrected"]
         out["kernels"] = ks
         tot = sum(v["ms"] for v in kern.values())
         out["kernel_time_share"] = {k: round(v["ms"] / tot, 4) for k, v in sorted(kern.items(), key=lambda kv: -kv[1]["ms"])[:8]}
@@ -352,6 +355,29 @@ def main():
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t1) / reps
         out["single_pair"] = {"workload": "BASELINE configs[1]: one 512x768 pair", "ms": round(dt * 1e3, 3), "pairs_per_s": round(1 / dt, 2)}
+
+    if not args.no_fast and world == 1 and args.precision == "fp32":
+        # secondary measurement: the opt-in split-bf16 mode on the same clip, with its flow error against the fp32 run
+        ref_flow = eng.forward(frames, key, iters=ITERS)
+        fast = RaftEngine(random_state_dict(0), dev, precision="bf16x3")
+
+        def fstep():
+            fl = fast.forward(frames, key, iters=ITERS)
+            ops.warp_and_mask(key_ai, fl, conf, warp_mode=args.warp_mode, thres=0.95, ksize=7)
+            return fl
+        fl = fstep()
+        epe = float((fl - ref_flow).pow(2).sum(-1).sqrt().mean())
+        emax = float((fl - ref_flow).pow(2).sum(-1).sqrt().max())
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            fstep()
+        torch.cuda.synchronize()
+        dtf = (time.perf_counter() - t1) / args.steps
+        out["fast_mode"] = {"precision": "bf16x3", "value": round(B / dtf, 3), "unit": "pairs/s", "ms_per_step": round(dtf * 1e3, 3),
+                            "flow_epe_vs_fp32_px": epe, "flow_max_err_vs_fp32_px": emax,
+                            "note": "opt-in; not the headline value (the reference computes in fp32)"}
+        del fast, ref_flow
 
     if not args.no_cpu_baseline and world == 1:
         # child process with a hard time limit: the baseline must never take the GPU number down with it

@@ -120,6 +120,13 @@ int ofx_warp_and_mask(const uint8_t* frame, long frame_bstride, const float* flo
 #define OFX_EPI_GRU_Q   2   /* q=tanh; h = (1-z)*h + z*q written in place to aux_h               */
 #define OFX_EPI_FLOW    3   /* Cout=2: coords1 += delta; flow=coords1-grid -> aux_h slot + flow4 */
 
+/* Arithmetic of the matrix-core contractions.  FP32 is the reference's (and the default): v_mfma_f32_32x32x2_f32,
+ * bit-identical to an fmaf chain.  BF16X3 is an opt-in fast mode: each fp32 operand is split on the fly into
+ * hi = bf16(x), lo = bf16(x - hi) and the product is formed as hi*hi + hi*lo + lo*hi on the bf16 matrix cores
+ * with fp32 accumulation (operands carry ~16 mantissa bits; measured end-to-end flow EPE ~1e-4 px). */
+#define OFX_PREC_FP32   0
+#define OFX_PREC_BF16X3 1
+
 typedef struct ofx_conv_desc {
     /* input: NHWC fp32, up to two channel segments (torch.cat along C without materialising) */
     const float* in0; int ld0; int c0;
@@ -137,7 +144,8 @@ typedef struct ofx_conv_desc {
     long a_zs, w_zs, o_zs; int nz;               /* batched-GEMM mode (nz>1): per-z strides in elements */
     int B, Hin, Win, Hout, Wout, Cout, KH, KW, stride, padH, padW;
     int act, epi;
-    int tile;                                    /* 0 = auto; else BM*1000+BN, e.g. 128128 */
+    int tile;                                    /* 0 = auto; else BK*1000000 + BM*1000 + BN, e.g. 16128128 */
+    int precision;                               /* OFX_PREC_FP32 (default, exact fp32 MFMA) or OFX_PREC_BF16X3 */
 } ofx_conv_desc;
 
 int ofx_conv2d(const ofx_conv_desc* d, void* stream);
@@ -196,6 +204,7 @@ size_t ofx_raft_workspace_bytes(const ofx_raft* r, int B, int H, int W);
 #define OFX_RAFT_SHARED_IMG2  2   /* image2 is ONE image shared by the whole batch (key frame)     */
 #define OFX_RAFT_SHARED_IMG1  4   /* image1 is ONE image shared by the whole batch                 */
 #define OFX_RAFT_ALT_CORR     8   /* on-the-fly local correlation instead of the volume (alt_cuda_corr) */
+#define OFX_RAFT_BF16X3      16   /* opt-in: split-bf16 matrix-core arithmetic for every convolution / the volume */
 
 /* RAFT.forward(test_mode=True): image1/image2 u8 [B,H,W,3] on device -> flow_up f32[B,H,W,2]
  * (flow on image1's grid pointing into image2) and, if non-NULL, flow_low f32[B,H/8,W/8,2]. */

@@ -39,7 +39,7 @@ class ConvDesc(C.Structure):
         ("B", C.c_int), ("Hin", C.c_int), ("Win", C.c_int), ("Hout", C.c_int), ("Wout", C.c_int),
         ("Cout", C.c_int), ("KH", C.c_int), ("KW", C.c_int), ("stride", C.c_int),
         ("padH", C.c_int), ("padW", C.c_int),
-        ("act", C.c_int), ("epi", C.c_int), ("tile", C.c_int),
+        ("act", C.c_int), ("epi", C.c_int), ("tile", C.c_int), ("precision", C.c_int),
     ]
 
 

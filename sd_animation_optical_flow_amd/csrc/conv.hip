@@ -75,7 +75,7 @@ __device__ __forceinline__ float apply_act_rt(float v, int act) {
     }
 }
 
-template <int BM, int BN, int WM, int WN, int EPI, bool NORM, int BK>
+template <int BM, int BN, int WM, int WN, int EPI, bool NORM, int BK, int PREC>
 __global__ __launch_bounds__(256) void igemm_kernel(const ConvK p) {
     constexpr int TM = WM / 32, TN = WN / 32;
     constexpr int WAVES_N = BN / WN;
@@ -84,7 +84,10 @@ __global__ __launch_bounds__(256) void igemm_kernel(const ConvK p) {
     constexpr int RPG = 256 / QPR;            // rows staged per pass of the 256 threads
     constexpr int A_PER = BM / RPG, B_PER = BN / RPG;
     static_assert(A_PER >= 1 && B_PER >= 1, "tile too small for this BK");
-    constexpr int STAGE = (BM + BN) * LDK;
+    // PREC = 1 (bf16x3): every fp32 operand element is staged as two bf16 values hi = bf16(x), lo = bf16(x - hi)
+    // (same 4 bytes per element); rows are BK bf16 + 16 B of padding (48 B / 80 B: conflict-free b128 reads)
+    constexpr int ROWB = BK * 2 + 16;                       // bytes per staged bf16 row
+    constexpr int STAGE = PREC ? ((BM + BN) * ROWB * 2) / 4 : (BM + BN) * LDK;   // floats per stage
     static_assert((BM / WM) * (BN / WN) == 4, "4 waves per workgroup");
     __shared__ __attribute__((aligned(16))) float smem[2 * STAGE];
 
@@ -222,24 +225,54 @@ __global__ __launch_bounds__(256) void igemm_kernel(const ConvK p) {
 #undef OFX_B_ISSUE
     };
 
-    auto commit = [&](float* As) __attribute__((always_inline)) {
-        float* Bs = As + BM * LDK;
-#pragma unroll
-        for (int i = 0; i < A_PER; ++i) {
-            float4 v = ra[i];
-            if (NORM) {   // instance norm + ReLU of the producer layer, applied on the fly; padding stays 0
-                v.x = fmaxf((v.x - rmu[i].x) * rrs[i].x, 0.f);
-                v.y = fmaxf((v.y - rmu[i].y) * rrs[i].y, 0.f);
-                v.z = fmaxf((v.z - rmu[i].z) * rrs[i].z, 0.f);
-                v.w = fmaxf((v.w - rmu[i].w) * rrs[i].w, 0.f);
-                if (!((okbits >> i) & 1u)) v = make_float4(0.f, 0.f, 0.f, 0.f);
-            }
-            *reinterpret_cast<float4*>(&As[(r0 + RPG * i) * LDK + kq * 4]) = v;
+    auto norm_a = [&](int i) __attribute__((always_inline)) -> float4 {
+        float4 v = ra[i];
+        if (NORM) {   // instance norm + ReLU of the producer layer, applied on the fly; padding stays 0
+            v.x = fmaxf((v.x - rmu[i].x) * rrs[i].x, 0.f);
+            v.y = fmaxf((v.y - rmu[i].y) * rrs[i].y, 0.f);
+            v.z = fmaxf((v.z - rmu[i].z) * rrs[i].z, 0.f);
+            v.w = fmaxf((v.w - rmu[i].w) * rrs[i].w, 0.f);
+            if (!((okbits >> i) & 1u)) v = make_float4(0.f, 0.f, 0.f, 0.f);
         }
+        return v;
+    };
+    // fp32 -> (hi, lo) bf16 pair, round-to-nearest-even both times (v_cvt_pk_bf16_f32): x = hi + lo + O(2^-17 |x|)
+    auto split_store = [&](char* hi_row, char* lo_row, float4 v) __attribute__((always_inline)) {
+        typedef float f4 __attribute__((ext_vector_type(4)));
+        typedef __bf16 b4 __attribute__((ext_vector_type(4)));
+        const f4 x = {v.x, v.y, v.z, v.w};
+        const b4 h = __builtin_convertvector(x, b4);
+        const f4 r = x - __builtin_convertvector(h, f4);
+        const b4 l = __builtin_convertvector(r, b4);
+        *reinterpret_cast<b4*>(hi_row) = h;
+        *reinterpret_cast<b4*>(lo_row) = l;
+    };
+
+    auto commit = [&](float* stage) __attribute__((always_inline)) {
+        if constexpr (PREC == 0) {
+            float* As = stage;
+            float* Bs = As + BM * LDK;
+#pragma unroll
+            for (int i = 0; i < A_PER; ++i) *reinterpret_cast<float4*>(&As[(r0 + RPG * i) * LDK + kq * 4]) = norm_a(i);
 #define OFX_B_COMMIT(i) \
     if constexpr (B_PER > i) *reinterpret_cast<float4*>(&Bs[(r0 + RPG * i) * LDK + kq * 4]) = rb##i;
-        OFX_B_COMMIT(0) OFX_B_COMMIT(1) OFX_B_COMMIT(2) OFX_B_COMMIT(3)
+            OFX_B_COMMIT(0) OFX_B_COMMIT(1) OFX_B_COMMIT(2) OFX_B_COMMIT(3)
 #undef OFX_B_COMMIT
+        } else {
+            char* a_hi = reinterpret_cast<char*>(stage);
+            char* a_lo = a_hi + BM * ROWB;
+            char* b_hi = a_lo + BM * ROWB;
+            char* b_lo = b_hi + BN * ROWB;
+#pragma unroll
+            for (int i = 0; i < A_PER; ++i) {
+                const int o = (r0 + RPG * i) * ROWB + kq * 8;
+                split_store(a_hi + o, a_lo + o, norm_a(i));
+            }
+#define OFX_B_COMMIT(i) \
+    if constexpr (B_PER > i) { const int o = (r0 + RPG * i) * ROWB + kq * 8; split_store(b_hi + o, b_lo + o, rb##i); }
+            OFX_B_COMMIT(0) OFX_B_COMMIT(1) OFX_B_COMMIT(2) OFX_B_COMMIT(3)
+#undef OFX_B_COMMIT
+        }
     };
 
     // ---- prologue: chunk 0 committed, chunk 1 in flight
@@ -254,26 +287,61 @@ __global__ __launch_bounds__(256) void igemm_kernel(const ConvK p) {
     //   buf[(kt+1)&1] -> barrier -> issue the loads of chunk kt+2 (they land during the next MFMA block)
     for (int kt = 0; kt < nk; ++kt) {
         offsets(min(kt + 2, nk - 1));
-        const float* As = smem + (kt & 1) * STAGE;
-        const float* Bs = As + BM * LDK;
+        if constexpr (PREC == 0) {
+            const float* As = smem + (kt & 1) * STAGE;
+            const float* Bs = As + BM * LDK;
 #pragma unroll
-        for (int ks = 0; ks < BK / 8; ++ks) {
-            float4 fa[TM], fb[TN];
+            for (int ks = 0; ks < BK / 8; ++ks) {
+                float4 fa[TM], fb[TN];
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
-                fa[i] = *reinterpret_cast<const float4*>(&As[(wm * WM + i * 32 + frag_row) * LDK + ks * 8 + frag_k]);
+                for (int i = 0; i < TM; ++i)
+                    fa[i] = *reinterpret_cast<const float4*>(&As[(wm * WM + i * 32 + frag_row) * LDK + ks * 8 + frag_k]);
 #pragma unroll
-            for (int j = 0; j < TN; ++j)
-                fb[j] = *reinterpret_cast<const float4*>(&Bs[(wn * WN + j * 32 + frag_row) * LDK + ks * 8 + frag_k]);
+                for (int j = 0; j < TN; ++j)
+                    fb[j] = *reinterpret_cast<const float4*>(&Bs[(wn * WN + j * 32 + frag_row) * LDK + ks * 8 + frag_k]);
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].x, fb[j].x, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].y, fb[j].y, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].z, fb[j].z, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].w, fb[j].w, acc[i][j], 0, 0, 0);
+                    }
+            }
+        } else {
+            // bf16x3: acc += a_hi*b_hi + a_hi*b_lo + a_lo*b_hi on v_mfma_f32_32x32x16_bf16 (fp32 accumulate).
+            // Lane l supplies row (l & 31) and the 8 consecutive k of group (l >> 5): one 16-byte LDS read per operand.
+            typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+            const char* a_hi = reinterpret_cast<const char*>(smem + (kt & 1) * STAGE);
+            const char* a_lo = a_hi + BM * ROWB;
+            const char* b_hi = a_lo + BM * ROWB;
+            const char* b_lo = b_hi + BN * ROWB;
+#pragma unroll
+            for (int ks = 0; ks < BK / 16; ++ks) {
+                bf16x8 ah[TM], al[TM], bh[TN], bl[TN];
+                const int ko = ks * 32 + (lane >> 5) * 16;
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    const int o = (wm * WM + i * 32 + frag_row) * ROWB + ko;
+                    ah[i] = *reinterpret_cast<const bf16x8*>(a_hi + o);
+                    al[i] = *reinterpret_cast<const bf16x8*>(a_lo + o);
+                }
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].x, fb[j].x, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].y, fb[j].y, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].z, fb[j].z, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].w, fb[j].w, acc[i][j], 0, 0, 0);
+                    const int o = (wn * WN + j * 32 + frag_row) * ROWB + ko;
+                    bh[j] = *reinterpret_cast<const bf16x8*>(b_hi + o);
+                    bl[j] = *reinterpret_cast<const bf16x8*>(b_lo + o);
                 }
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                    }
+            }
         }
         // chunk kt+1 has had a whole MFMA block to land; on the last iteration this rewrites the idle
         // buffer with a duplicate that nobody reads
@@ -335,18 +403,18 @@ __global__ __launch_bounds__(256) void igemm_kernel(const ConvK p) {
     }
 }
 
-template <int BM, int BN, int WM, int WN, int BK>
+template <int BM, int BN, int WM, int WN, int BK, int PREC = 0>
 int launch_tile(const ConvK& k, int epi, bool norm, int nz, hipStream_t s) {
     dim3 grid((unsigned)(k.mtiles * k.ntiles), (unsigned)nz, 1);
     dim3 block(256, 1, 1);
     switch (epi) {
         case OFX_EPI_PLAIN:
-            if (norm) hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, OFX_EPI_PLAIN, true, BK>), grid, block, 0, s, k);
-            else hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, OFX_EPI_PLAIN, false, BK>), grid, block, 0, s, k);
+            if (norm) hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, OFX_EPI_PLAIN, true, BK, PREC>), grid, block, 0, s, k);
+            else hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, OFX_EPI_PLAIN, false, BK, PREC>), grid, block, 0, s, k);
             break;
-        case OFX_EPI_GRU_ZR: hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, OFX_EPI_GRU_ZR, false, BK>), grid, block, 0, s, k); break;
-        case OFX_EPI_GRU_Q: hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, OFX_EPI_GRU_Q, false, BK>), grid, block, 0, s, k); break;
-        case OFX_EPI_FLOW: hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, OFX_EPI_FLOW, false, BK>), grid, block, 0, s, k); break;
+        case OFX_EPI_GRU_ZR: hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, OFX_EPI_GRU_ZR, false, BK, PREC>), grid, block, 0, s, k); break;
+        case OFX_EPI_GRU_Q: hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, OFX_EPI_GRU_Q, false, BK, PREC>), grid, block, 0, s, k); break;
+        case OFX_EPI_FLOW: hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, OFX_EPI_FLOW, false, BK, PREC>), grid, block, 0, s, k); break;
         default: return OFX_EINVAL;
     }
     return ofx_launch_status();
@@ -453,6 +521,12 @@ extern "C" int ofx_conv2d_alpha(const ofx_conv_desc* d, float alpha, void* strea
     // extra resident wave per SIMD hides the commit/barrier/issue phases better than a longer chunk does
     // (measured +4..10 % on every shape).  tile = BK*1e6 + BM*1e3 + BN overrides.
     const int bk = d->tile >= 1000000 ? d->tile / 1000000 : (bn == 32 ? 32 : 16);
+    if (d->precision == OFX_PREC_BF16X3) {
+        // split-bf16 matrix-core path (opt-in): the three tiles below; anything else falls through to fp32
+        if (bm == 128 && bn == 128) return launch_tile<128, 128, 64, 64, 16, 1>(k, d->epi, norm, nz, s);
+        if (bm == 128 && bn == 64) return launch_tile<128, 64, 64, 32, 16, 1>(k, d->epi, norm, nz, s);
+        if (bm == 64 && bn == 64) return launch_tile<64, 64, 32, 32, 16, 1>(k, d->epi, norm, nz, s);
+    }
     if (bm == 128 && bn == 128 && bk == 16) return launch_tile<128, 128, 64, 64, 16>(k, d->epi, norm, nz, s);
     if (bm == 128 && bn == 64 && bk == 16) return launch_tile<128, 64, 64, 32, 16>(k, d->epi, norm, nz, s);
     if (bm == 128 && bn == 128) return launch_tile<128, 128, 64, 64, 32>(k, d->epi, norm, nz, s);

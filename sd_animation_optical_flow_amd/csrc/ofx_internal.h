@@ -48,6 +48,8 @@ int ofx_mask_bits_launch(int src, const float* conf, float* log_conf, const uint
                          const char* name, hipStream_t s);
 int ofx_init_state(float* coords1, float* flow4, float* hx, int ldh, int flow_off, int B, int h, int w, hipStream_t s);
 int ofx_coords_to_flow(const float* coords1, float* flow, int B, int h, int w, hipStream_t s);
+int ofx_flow_head_launch(const float* x, int ldx, const float* w, int Kpad, const float* bias, float* coords1, float* hx_flow,
+                         int ldh, float* flow4, int B, int h, int w_, hipStream_t s);
 int ofx_ctx_gather(const float* ctx, const int* idx_dev, float* hx, int ldh, int off2, int half, int B, long N, hipStream_t s);
 
 // ---- device helpers --------------------------------------------------------------------

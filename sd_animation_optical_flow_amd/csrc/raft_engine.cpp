@@ -241,6 +241,7 @@ struct Launcher {
     int st = 0;
     const float* addend = nullptr;   // consumed (and cleared) by the next conv() call
     int ldadd = 0;
+    int precision = OFX_PREC_FP32;   // sticky: OFX_PREC_BF16X3 when the forward was asked for the split-bf16 mode
     // generic conv launch; all pointer plumbing in one place
     void conv(const ConvW& c, const float* in0, int ld0, int c0, const float* in1, int ld1, int c1, float* out, int ldo,
               int B, int Hin, int Win, int stride, int act, int epi = OFX_EPI_PLAIN, const float* res = nullptr,
@@ -268,6 +269,7 @@ struct Launcher {
         d.Wout = (Win + 2 * padW - c.kw) / stride + 1;
         d.Cout = cout; d.KH = c.kh; d.KW = c.kw; d.stride = stride; d.padH = padH; d.padW = padW;
         d.act = act; d.epi = epi;
+        d.precision = precision;
         if (c0 + c1 != c.cin_pad) { st = OFX_EKEY; return; }
         st = ofx_conv2d(&d, s);
     }
@@ -283,9 +285,11 @@ struct EncBufs {
 
 // --------------------------------------------------------------------------------------------
 static int run_encoder(ofx_raft* r, const std::string& enc, bool bn, const uint8_t* imgs, int n, int H, int W,
-                       int bgr, const EncBufs& eb, float* out, int out_ld, bool split_tanh_relu, int relu_off, hipStream_t s) {
+                       int bgr, const EncBufs& eb, float* out, int out_ld, bool split_tanh_relu, int relu_off, hipStream_t s,
+                       int precision = OFX_PREC_FP32) {
     // `out`: [n*h*w][out_ld]; fnet writes 256 channels; cnet writes tanh(0:128) | relu(128:256)
     Launcher L{s};
+    L.precision = precision;
     const int H2 = H / 2, W2 = W / 2, H4 = H / 4, W4 = W / 4, H8 = H / 8, W8 = W / 8;
     const int SC = ENC_CHUNK * 128;   // floats per stats vector slot
     float* m1 = eb.stats + 0 * SC; float* s1 = eb.stats + 1 * SC;
@@ -418,7 +422,7 @@ static RaftWs carve(void* base, size_t cap, int B, int H, int W, int flags, int 
 // everything after the feature / context encoders and the correlation volume: state init, the loop-invariant
 // GRU terms, `iters` refinement iterations, mask head, convex upsample
 static int run_recurrence(ofx_raft* r, const RaftWs& ws, int B, int h, int w, int iters, bool alt, bool shared,
-                          float* flow_up, float* flow_low, hipStream_t s) {
+                          float* flow_up, float* flow_low, hipStream_t s, int precision = OFX_PREC_FP32) {
     const long N = (long)h * w;
     const bool sh1 = shared, sh2 = shared;
     int st = 0;
@@ -426,6 +430,7 @@ static int run_recurrence(ofx_raft* r, const RaftWs& ws, int B, int h, int w, in
     if (st) return st;
     {   // loop-invariant GRU terms: conv(W[:, inp], inp) + bias for z|r and q of both passes
         Launcher G{s};
+        G.precision = precision;
         const char* names[4] = {"gru.zr1.inp", "gru.q1.inp", "gru.zr2.inp", "gru.q2.inp"};
         const int offs[4] = {0, 2 * HD, 3 * HD, 5 * HD};
         for (int i = 0; i < 4; ++i)
@@ -435,6 +440,7 @@ static int run_recurrence(ofx_raft* r, const RaftWs& ws, int B, int h, int w, in
     }
 
     Launcher L{s};
+    L.precision = precision;
     auto C = [&](const char* k) -> const ConvW& { return r->convs[k]; };
     const float* pyr_c[LEVELS] = {ws.pyr[0], ws.pyr[1], ws.pyr[2], ws.pyr[3]};
     const int rd2 = (2 * RADIUS + 1) * (2 * RADIUS + 1);
@@ -470,8 +476,11 @@ static int run_recurrence(ofx_raft* r, const RaftWs& ws, int B, int h, int w, in
         }
         // flow head (update.py:6-14) + coords1 += delta (raft.py:131) in the epilogue
         L.conv(C("fh1"), ws.hx, HX_LD, HD, nullptr, 0, 0, ws.c1, 256, B, h, w, 1, OFX_ACT_RELU);
-        L.conv(C("fh2"), ws.c1, 256, 256, nullptr, 0, 0, nullptr, 0, B, h, w, 1, OFX_ACT_NONE, OFX_EPI_FLOW, nullptr, 0,
-               nullptr, nullptr, nullptr, nullptr, ws.hx + FLOW_OFF, HX_LD, ws.coords1, ws.flow4);
+        if (!L.st) {   // 256 -> 2 channels: dedicated reduction kernel instead of a 1/16-utilised GEMM tile
+            const ConvW& f2 = C("fh2");
+            L.st = ofx_flow_head_launch(ws.c1, 256, f2.w, (int)f2.kpad, f2.shift, ws.coords1, ws.hx + FLOW_OFF, HX_LD, ws.flow4, B, h,
+                                        w, s);
+        }
     }
     // mask head (update.py:122-125,135) on the final hidden state, then convex upsample
     L.conv(C("mask0"), ws.hx, HX_LD, HD, nullptr, 0, 0, ws.c1, 256, B, h, w, 1, OFX_ACT_RELU);
@@ -560,6 +569,7 @@ int ofx_raft_forward(ofx_raft* r, const uint8_t* image1, const uint8_t* image2, 
     const long N = (long)h * w;
     const long M = (long)B * N;
     const int bgr = (flags & OFX_RAFT_BGR) ? 1 : 0;
+    const int prec = (flags & OFX_RAFT_BF16X3) ? OFX_PREC_BF16X3 : OFX_PREC_FP32;
     const bool sh1 = flags & OFX_RAFT_SHARED_IMG1, sh2 = flags & OFX_RAFT_SHARED_IMG2;
     const bool alt = flags & OFX_RAFT_ALT_CORR;
     const long img_bytes = (long)H * W * 3;
@@ -570,16 +580,16 @@ int ofx_raft_forward(ofx_raft* r, const uint8_t* image1, const uint8_t* image2, 
     for (int i0 = 0; i0 < n1 && !st; i0 += ENC_CHUNK) {
         const int n = std::min(ENC_CHUNK, n1 - i0);
         st = run_encoder(r, "fnet", false, image1 + i0 * img_bytes, n, H, W, bgr, ws.eb, ws.fmap1 + (long)i0 * N * FD, FD,
-                         false, 0, s);
+                         false, 0, s, prec);
     }
     for (int i0 = 0; i0 < n2 && !st; i0 += ENC_CHUNK) {
         const int n = std::min(ENC_CHUNK, n2 - i0);
         st = run_encoder(r, "fnet", false, image2 + i0 * img_bytes, n, H, W, bgr, ws.eb, ws.fmap2 + (long)i0 * N * FD, FD,
-                         false, 0, s);
+                         false, 0, s, prec);
     }
     // ---- context encoder on image1 -> hx[:, 0:128] = tanh (net), hx[:, 256:384] = relu (inp)
     if (sh1) {
-        if (!st) st = run_encoder(r, "cnet", true, image1, 1, H, W, bgr, ws.eb, ws.hx, HX_LD, true, INP_OFF, s);
+        if (!st) st = run_encoder(r, "cnet", true, image1, 1, H, W, bgr, ws.eb, ws.hx, HX_LD, true, INP_OFF, s, prec);
         for (int k = 1; k < B && !st; ++k)   // one shared image1: replicate its context rows
             OFX_HIP_CHECK(hipMemcpyAsync(ws.hx + (long)k * N * HX_LD, ws.hx, (size_t)N * HX_LD * sizeof(float),
                                          hipMemcpyDeviceToDevice, s));
@@ -587,7 +597,7 @@ int ofx_raft_forward(ofx_raft* r, const uint8_t* image1, const uint8_t* image2, 
         for (int i0 = 0; i0 < B && !st; i0 += ENC_CHUNK) {
             const int n = std::min(ENC_CHUNK, B - i0);
             st = run_encoder(r, "cnet", true, image1 + i0 * img_bytes, n, H, W, bgr, ws.eb, ws.hx + (long)i0 * N * HX_LD,
-                             HX_LD, true, INP_OFF, s);
+                             HX_LD, true, INP_OFF, s, prec);
         }
     }
     if (st) return st;
@@ -602,6 +612,7 @@ int ofx_raft_forward(ofx_raft* r, const uint8_t* image1, const uint8_t* image2, 
         d.B = 1; d.Hin = h; d.Win = w; d.Hout = h; d.Wout = w; d.Cout = (int)N;
         d.KH = 1; d.KW = 1; d.stride = 1;
         d.act = OFX_ACT_NONE; d.epi = OFX_EPI_PLAIN;
+        d.precision = prec;
         // zero batch strides broadcast a shared key-frame feature map across the batch
         st = ofx_conv2d_alpha(&d, 1.0f / std::sqrt((float)FD), s);
         if (!st) st = ofx_corr_pool_launch(ws.pyr[0], ws.pyr[1], ws.pyr[2], ws.pyr[3], B, h, w, LEVELS, s);
@@ -612,7 +623,7 @@ int ofx_raft_forward(ofx_raft* r, const uint8_t* image1, const uint8_t* image2, 
         if (st) return st;
     }
 
-    st = run_recurrence(r, ws, B, h, w, iters, alt, sh1 || sh2, flow_up, flow_low, s);
+    st = run_recurrence(r, ws, B, h, w, iters, alt, sh1 || sh2, flow_up, flow_low, s, prec);
     if (st) return st;
 
     r->bufs.clear();
@@ -653,6 +664,7 @@ int ofx_raft_forward_pairs(ofx_raft* r, const uint8_t* images, int n_images, con
     const int h = H / 8, w = W / 8;
     const long N = (long)h * w;
     const int bgr = (flags & OFX_RAFT_BGR) ? 1 : 0;
+    const int prec = (flags & OFX_RAFT_BF16X3) ? OFX_PREC_BF16X3 : OFX_PREC_FP32;
     const long img_bytes = (long)H * W * 3;
     int st = 0;
     // every image is encoded ONCE (feature + context), however many pairs it takes part in: a 15-frame
@@ -660,10 +672,10 @@ int ofx_raft_forward_pairs(ofx_raft* r, const uint8_t* images, int n_images, con
     for (int i0 = 0; i0 < n_images && !st; i0 += ENC_CHUNK) {
         const int n = std::min(ENC_CHUNK, n_images - i0);
         st = run_encoder(r, "fnet", false, images + i0 * img_bytes, n, H, W, bgr, ws.eb, ws.fmap1 + (long)i0 * N * FD, FD, false,
-                         0, s);
+                         0, s, prec);
         if (!st)
             st = run_encoder(r, "cnet", true, images + i0 * img_bytes, n, H, W, bgr, ws.eb, ws.ctx + (long)i0 * N * (HD + CD),
-                             HD + CD, true, HD, s);
+                             HD + CD, true, HD, s, prec);
     }
     if (st) return st;
     OFX_HIP_CHECK(hipMemcpyAsync(ws.idx_dev, idx1, sizeof(int) * B, hipMemcpyHostToDevice, s));
@@ -677,11 +689,12 @@ int ofx_raft_forward_pairs(ofx_raft* r, const uint8_t* images, int n_images, con
         d.B = 1; d.Hin = h; d.Win = w; d.Hout = h; d.Wout = w; d.Cout = (int)N;
         d.KH = 1; d.KW = 1; d.stride = 1;
         d.act = OFX_ACT_NONE; d.epi = OFX_EPI_PLAIN;
+        d.precision = prec;
         st = ofx_conv2d_alpha(&d, 1.0f / std::sqrt((float)FD), s);
     }
     if (!st) st = ofx_corr_pool_launch(ws.pyr[0], ws.pyr[1], ws.pyr[2], ws.pyr[3], B, h, w, LEVELS, s);
     if (st) return st;
-    st = run_recurrence(r, ws, B, h, w, iters, false, false, flow_up, flow_low, s);
+    st = run_recurrence(r, ws, B, h, w, iters, false, false, flow_up, flow_low, s, prec);
     if (st) return st;
     r->bufs.clear();
     return 0;

@@ -229,7 +229,8 @@ def pack_conv_weight(w_oihw: torch.Tensor, cin_pad: Optional[int] = None) -> tor
 def conv2d_nhwc(x: torch.Tensor, w_packed: torch.Tensor, kh: int, kw: int, cout: int, *, stride: int = 1,
                 shift: Optional[torch.Tensor] = None, scale: Optional[torch.Tensor] = None, act: Optional[str] = None,
                 x2: Optional[torch.Tensor] = None, res: Optional[torch.Tensor] = None,
-                nmean: Optional[torch.Tensor] = None, nrstd: Optional[torch.Tensor] = None, tile: int = 0) -> torch.Tensor:
+                nmean: Optional[torch.Tensor] = None, nrstd: Optional[torch.Tensor] = None, tile: int = 0,
+                precision: str = "fp32") -> torch.Tensor:
     """Plain-epilogue convolution: x [B,H,W,C0] (+ optional second channel segment x2 [B,H,W,C1]),
     'same' padding (k//2).  Returns [B,Hout,Wout,cout]."""
     x = _chk(x, "x", torch.float32)
@@ -256,6 +257,7 @@ def conv2d_nhwc(x: torch.Tensor, w_packed: torch.Tensor, kh: int, kw: int, cout:
     d.B, d.Hin, d.Win, d.Hout, d.Wout, d.Cout = B, H, W, Ho, Wo, cout
     d.KH, d.KW, d.stride, d.padH, d.padW = kh, kw, stride, ph, pw
     d.act, d.epi, d.tile = ACTS[act], EPI_PLAIN, tile
+    d.precision = {"fp32": 0, "bf16x3": 1}[precision]
     check(_lib.lib().ofx_conv2d(C.byref(d), _stream()), "ofx_conv2d")
     return out
 

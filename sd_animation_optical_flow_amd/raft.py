@@ -16,11 +16,18 @@ import torch.nn.functional as F
 from . import _lib
 from ._lib import check
 
-FLAG_BGR, FLAG_SHARED_IMG2, FLAG_SHARED_IMG1, FLAG_ALT_CORR = 1, 2, 4, 8
+FLAG_BGR, FLAG_SHARED_IMG2, FLAG_SHARED_IMG1, FLAG_ALT_CORR, FLAG_BF16X3 = 1, 2, 4, 8, 16
+PRECISIONS = {"fp32": 0, "bf16x3": FLAG_BF16X3}
 
 
 class RaftEngine:
-    def __init__(self, state_dict: Dict[str, torch.Tensor], device: Optional[torch.device] = None):
+    def __init__(self, state_dict: Dict[str, torch.Tensor], device: Optional[torch.device] = None, precision: str = "fp32"):
+        """precision: 'fp32' (default; exact fp32 matrix-core arithmetic, the reference's) or 'bf16x3' (opt-in fast
+        mode: operands split into two bf16 values, three bf16 MFMAs per product, fp32 accumulate; flow EPE
+        ~1e-4 px against the fp32 path)."""
+        if precision not in PRECISIONS:
+            raise ValueError(f"precision must be one of {sorted(PRECISIONS)}")
+        self.precision = precision
         L = _lib.lib()
         if not torch.cuda.is_available():
             raise RuntimeError("RaftEngine needs a HIP device (no CPU fallback)")
@@ -91,7 +98,7 @@ class RaftEngine:
                 raise RuntimeError(f"{nm} must be a CUDA tensor")
             if t.dtype != torch.uint8:
                 raise RuntimeError(f"{nm} must be uint8")
-        flags = FLAG_BGR if bgr else 0
+        flags = (FLAG_BGR if bgr else 0) | PRECISIONS[self.precision]
         sh1, sh2 = image1.dim() == 3, image2.dim() == 3
         if sh1 and sh2:
             image1, sh1 = image1[None], False
@@ -110,6 +117,20 @@ class RaftEngine:
             flags |= FLAG_SHARED_IMG2
         if alternate_corr:
             flags |= FLAG_ALT_CORR
+        # the conv kernels address their inputs with 32-bit byte offsets (buffer descriptors): the widest
+        # input (the 384-channel GRU state row) must stay below 2 GiB -> larger batches are processed in
+        # slices (pairs are independent)
+        max_pairs = max(1, ((1 << 31) - 4096) // ((H // 8) * (W // 8) * 384 * 4))
+        if B > max_pairs:
+            ups, lows = [], []
+            for b0 in range(0, B, max_pairs):
+                a = image1 if sh1 else image1[b0:b0 + max_pairs]
+                c = image2 if sh2 else image2[b0:b0 + max_pairs]
+                r = self.forward(a, c, iters=iters, bgr=bgr, alternate_corr=alternate_corr, want_low=want_low)
+                ups.append(r[0] if want_low else r)
+                if want_low:
+                    lows.append(r[1])
+            return (torch.cat(ups), torch.cat(lows)) if want_low else torch.cat(ups)
         ws = self._workspace(B, H, W)
         flow_up = torch.empty((B, H, W, 2), dtype=torch.float32, device=self.device)
         flow_low = torch.empty((B, H // 8, W // 8, 2), dtype=torch.float32, device=self.device) if want_low else None
@@ -146,7 +167,7 @@ class RaftEngine:
         flow_up = torch.empty((B, H, W, 2), dtype=torch.float32, device=self.device)
         stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
         check(L.ofx_raft_forward_pairs(self._h, C.c_void_p(imgs.data_ptr()), n, a1, a2, B, H, W, int(iters),
-                                       FLAG_BGR if bgr else 0, C.c_void_p(flow_up.data_ptr()), None,
+                                       (FLAG_BGR if bgr else 0) | PRECISIONS[self.precision], C.c_void_p(flow_up.data_ptr()), None,
                                        C.c_void_p(self._ws.data_ptr()), self._ws.numel(), stream), "ofx_raft_forward_pairs")
         return flow_up
 

@@ -78,6 +78,26 @@ def test_conv2d_matches_torch(cuda, case):
     assert err < 2e-5, err      # fp32 accumulate, K <= 3456
 
 
+@pytest.mark.parametrize("case", [(2, 24, 20, 64, 64, 3, 3, 1), (1, 33, 17, 256, 256, 1, 5, 1), (1, 16, 16, 324, 256, 1, 1, 1),
+                                  (1, 40, 24, 96, 192, 3, 3, 2)])
+def test_conv2d_bf16x3_mode(cuda, case):
+    """Opt-in split-bf16 arithmetic: operands carry ~16 mantissa bits -> relative error ~1e-5 of the output scale."""
+    ops = _ops()
+    B, H, W, ci, co, kh, kw, stride = case
+    g = torch.Generator().manual_seed(sum(case))
+    x = torch.randn((B, ci, H, W), generator=g)
+    w = torch.randn((co, ci, kh, kw), generator=g) / np.sqrt(ci * kh * kw)
+    b = torch.randn((co,), generator=g)
+    ref = F.conv2d(x.double(), w.double(), b.double(), stride=stride, padding=(kh // 2, kw // 2)).float()
+    wp = ops.pack_conv_weight(w).cuda()
+    out32 = ops.conv2d_nhwc(nhwc(x), wp, kh, kw, co, stride=stride, shift=b.cuda())
+    out16 = ops.conv2d_nhwc(nhwc(x), wp, kh, kw, co, stride=stride, shift=b.cuda(), precision="bf16x3")
+    e32 = (nchw(out32) - ref).abs().max().item()
+    e16 = (nchw(out16) - ref).abs().max().item()
+    assert e32 < 2e-5 and e16 < 2e-4, (e32, e16)          # outputs are O(1): 16-bit operands -> ~1e-5 .. 1e-4
+    assert e16 > 0                                           # and it really is a different arithmetic
+
+
 def test_conv2d_two_segments_residual_and_scale(cuda):
     ops = _ops()
     g = torch.Generator().manual_seed(3)

@@ -123,6 +123,19 @@ def test_forward_pairs_encodes_each_image_once(engine, raft_sd):
         engine.forward_pairs(imgs.cuda(), [0, 9], [1, 1])    # index out of range -> OFX_EINVAL
 
 
+def test_bf16x3_fast_mode_stays_inside_the_epe_bar(cuda, raft_sd):
+    """The opt-in split-bf16 mode: flow EPE vs the fp32 oracle must stay below the 1e-3 px parity bar."""
+    from sd_animation_optical_flow_amd.raft import RaftEngine
+    fast = RaftEngine(raft_sd, precision="bf16x3")
+    for (H, W, B, seed) in ((128, 160, 2, 11), (256, 384, 1, 12)):
+        key, frames = _frames(seed, B, H, W)
+        _, up_ref = _oracle_flow(raft_sd, frames, key[None].repeat(B, 1, 1, 1), 20)
+        up = fast.forward(frames.cuda(), key.cuda(), iters=20)
+        epe = _epe(up.cpu(), up_ref)
+        assert epe < 1e-3, epe
+        assert epe > 1e-6            # not the fp32 path by accident
+
+
 def test_non_multiple_of_8_is_padded_like_input_padder(engine, raft_sd):
     H, W = 100, 90
     key, frames = _frames(5, 1, H, W)

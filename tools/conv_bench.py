@@ -14,7 +14,17 @@ SHAPES = [  # name, B, H, W, Cin, Cout, kh, kw, stride, tile
     ("enc 3x3 64->64 @1/2", 16, 384, 256, 64, 64, 3, 3, 1, 0),
     ("enc 3x3 96->96 @1/4", 16, 192, 128, 96, 96, 3, 3, 1, 0),
 ]
-TILES = [0, 128128, 16128128, 128064, 16128064]
+TILES = [0, 128128, 16128128, 128064, 16128064, 64064, 16064064]
+if os.environ.get("CONV_BENCH_B1"):
+    SHAPES = [
+        ("b1 gru 1x5 256->256", 1, 96, 64, 256, 256, 1, 5, 1, 0),
+        ("b1 gru 5x1 256->128", 1, 96, 64, 256, 128, 5, 1, 1, 0),
+        ("b1 3x3 256->192", 1, 96, 64, 256, 192, 3, 3, 1, 0),
+        ("b1 3x3 128->256", 1, 96, 64, 128, 256, 3, 3, 1, 0),
+        ("b1 1x1 324->256", 1, 96, 64, 324, 256, 1, 1, 1, 0),
+        ("b1 enc 3x3 64->64 @1/2", 1, 384, 256, 64, 64, 3, 3, 1, 0),
+        ("b1 enc 3x3 128->128 @1/8", 1, 96, 64, 128, 128, 3, 3, 1, 0),
+    ]
 
 
 def run(libpath):
@@ -35,6 +45,7 @@ def run(libpath):
             d.B, d.Hin, d.Win, d.Hout, d.Wout, d.Cout = B, H, W, H // st, W // st, co
             d.KH, d.KW, d.stride, d.padH, d.padW = kh, kw, st, kh // 2, kw // 2
             d.act, d.epi, d.tile = 1, 0, tile
+            d.precision = int(os.environ.get('CONV_BENCH_PREC', '0'))
             s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
             for _ in range(3):
                 assert lib.ofx_conv2d(C.byref(d), s) == 0
