@@ -523,6 +523,7 @@ extern "C" int ofx_conv2d_alpha(const ofx_conv_desc* d, float alpha, void* strea
     const int bk = d->tile >= 1000000 ? d->tile / 1000000 : (bn == 32 ? 32 : 16);
     if (d->precision == OFX_PREC_BF16X3) {
         // split-bf16 matrix-core path (opt-in): the three tiles below; anything else falls through to fp32
+        if (bm == 128 && bn == 128 && d->tile >= 32000000) return launch_tile<128, 128, 64, 64, 32, 1>(k, d->epi, norm, nz, s);
         if (bm == 128 && bn == 128) return launch_tile<128, 128, 64, 64, 16, 1>(k, d->epi, norm, nz, s);
         if (bm == 128 && bn == 64) return launch_tile<128, 64, 64, 32, 16, 1>(k, d->epi, norm, nz, s);
         if (bm == 64 && bn == 64) return launch_tile<64, 64, 32, 32, 16, 1>(k, d->epi, norm, nz, s);

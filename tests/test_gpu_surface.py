@@ -179,3 +179,42 @@ def test_pdcnet_aux_pair_cache(algo, tmp_path):
     assert pw.shape == (2, 2, 64, 64, 3) and np.array_equal(pw[0, 1], on_disk)
     scores = aux2.keyframe_scores(pw)
     assert np.allclose(scores, MO.keyframe_scores(pw), rtol=1e-6)
+
+
+def test_frame_synthesizer_and_process_clip_device_path(algo, raft_sd):
+    """The device-resident tail (flow -> warp -> mask without leaving HBM) and the single-rank clip driver."""
+    from sd_animation_optical_flow_amd import clip
+    H, W, T = 96, 128, 5
+    a, _ = _pair(10, H, W)
+    key = torch.from_numpy(a[:, :, ::-1].copy()).cuda()                      # RGB key frame
+    frames = torch.stack([torch.roll(key, shifts=(t - 2, 2 - t), dims=(0, 1)) for t in range(T)]).contiguous()
+    key_ai = (255 - key).contiguous()
+    synth = clip.FrameSynthesizer(algo, warp_mode="cv2_cubic", thres=0.95, ksize=7)
+    res = clip.process_clip(frames, key, key_ai, synth, batch_size=2)
+    assert res.frame_indices == list(range(T)) and [t.shape[0] for t in res.flow] == [2, 2, 1]
+    flow = torch.cat(res.flow)
+    warped = torch.cat(res.warped)
+    mask = torch.cat(res.mask)
+    assert flow.is_cuda and warped.is_cuda and mask.is_cuda                   # nothing left the device
+    # same numbers as the host-side reference-style calls
+    f0, c0, _ = algo.calc(a, np.ascontiguousarray(frames[0].cpu().numpy()[:, :, ::-1]))      # (source=key, target=frame 0), BGR
+    assert np.abs(flow[0].cpu().numpy() - f0).max() < 1e-4
+    assert np.array_equal(warped[0].cpu().numpy(), WO.warp_frame(key_ai.cpu().numpy(), flow[0].cpu().numpy(), "cv2_cubic"))
+    ref_mask, _ = MO.generate_mask(c0, c0.copy(), 0.95, 7)
+    assert (mask[0].cpu().numpy() != ref_mask).mean() < 2e-3                  # confidence agrees to ~1e-6: masks differ only at exact ties
+
+
+def test_large_frame_1024x1024_single_pair(cuda, raft_sd):
+    """BASELINE config #5 frame size (flow part): 128x128 coarse grid, 1.43 GB pyramid, finite and self-consistent."""
+    from sd_animation_optical_flow_amd.raft import RaftEngine
+    eng = RaftEngine(raft_sd)
+    H = W = 1024
+    g = torch.Generator().manual_seed(5)
+    base = torch.nn.functional.avg_pool2d(torch.rand((1, 3, H + 16, W + 16), generator=g), 7, 1, 3)
+    base = ((base - base.min()) / (base.max() - base.min()) * 255).round().to(torch.uint8)
+    a = base[0, :, 8:8 + H, 8:8 + W].permute(1, 2, 0).contiguous().cuda()
+    b = base[0, :, 11:11 + H, 6:6 + W].permute(1, 2, 0).contiguous().cuda()
+    up, lo = eng.forward(a[None], b[None], iters=4, want_low=True)
+    assert tuple(up.shape) == (1, H, W, 2) and torch.isfinite(up).all()
+    # the convex upsample of a constant field is the constant field x 8: check on the coarse flow's interior mean
+    assert abs(float(up[0, 64:-64, 64:-64].mean()) / max(abs(float(lo[0, 8:-8, 8:-8].mean())), 1e-6) - 8.0) < 1.0

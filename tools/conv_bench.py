@@ -15,6 +15,8 @@ SHAPES = [  # name, B, H, W, Cin, Cout, kh, kw, stride, tile
     ("enc 3x3 96->96 @1/4", 16, 192, 128, 96, 96, 3, 3, 1, 0),
 ]
 TILES = [0, 128128, 16128128, 128064, 16128064, 64064, 16064064]
+if os.environ.get('CONV_BENCH_TILES'):
+    TILES = [int(t) for t in os.environ['CONV_BENCH_TILES'].split(',')]
 if os.environ.get("CONV_BENCH_B1"):
     SHAPES = [
         ("b1 gru 1x5 256->256", 1, 96, 64, 256, 256, 1, 5, 1, 0),
