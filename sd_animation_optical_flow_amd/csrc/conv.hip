@@ -8,24 +8,29 @@
 //   * the all-pairs correlation volume (RAFT/core/corr.py:52-60) as a batched 1x1 "conv" whose
 //     weights are the second feature map.
 //
-// Arithmetic is exact fp32: v_mfma_f32_32x32x2_f32 (f32 in, f32 accumulate, bit-identical to an
-// fmaf chain, 157 TFLOP/s peak = the roofline of this kernel).  The reference runs fp32
-// (mixed_precision=False, ofgen_keyframe_inpaint.py:57) and the parity bar is EPE <= 1e-3 px after
-// 20 recurrent iterations, so no reduced-precision operand format is used.
+// Arithmetic (template PREC):
+//   PREC = 0  exact fp32: v_mfma_f32_32x32x2_f32 (f32 in, f32 accumulate, bit-identical to an fmaf
+//             chain, 157 TFLOP/s peak = the roofline of this kernel).  The reference runs fp32
+//             (mixed_precision=False, ofgen_keyframe_inpaint.py:57); this is the default everywhere.
+//   PREC = 1  opt-in "bf16x3": every operand is split at LDS-commit time into hi = bf16(x) and
+//             lo = bf16(x - hi); hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_bf16, f32 accumulate
+//             (~16 mantissa bits per product; measured flow EPE ~1e-4 px after 20 iterations).
 //
-// Tiling (64-wide wavefronts): 256 threads = 4 waves per workgroup, a BMxBN output tile, BK = 32.
-// Both operands are staged k-contiguous in LDS with a row stride of 36 floats, which makes the
-// per-lane ds_read_b128 fragment reads conflict-free; each b128 read feeds four MFMAs (lane half h
-// supplies k = 8*ks + 4*h + s for s = 0..3 -- the k order inside a chunk is permuted identically for
-// A and B, which leaves the dot product unchanged).
+// Tiling (64-wide wavefronts): 256 threads = 4 waves per workgroup, a BMxBN output tile, BK = 16 or
+// 32.  Both operands are staged k-contiguous in LDS with a row stride of BK+4 floats (20 / 36), which
+// makes the per-lane ds_read_b128 fragment reads conflict-free; each b128 read feeds four fp32 MFMAs
+// (lane half h supplies k = 8*ks + 4*h + s for s = 0..3 -- the k order inside a chunk is permuted
+// identically for A and B, which leaves the dot product unchanged).  BK = 16 keeps a 128x128 tile at
+// 40 KB of LDS so three workgroups share a CU.
 //
 // Pipeline (one barrier per K-chunk, two LDS buffers, two chunks of global loads in flight):
 //     MFMA block on buf[cur]  ->  commit registers (chunk kt+1) to buf[cur^1]  ->  barrier  ->
 //     issue global loads of chunk kt+2
-// The loads are branch-free (addresses clamped into the tensor, padding / K-tail zeroed by a select at
-// commit time), so all 8 of a thread's 16-byte loads are in flight together and have a full MFMA
-// block (1-4k cycles) to land.  The linear block id is remapped so that the N-tiles sharing an A tile
-// run on the same XCD (private L2).
+// The gather is branch-free: operands are read through buffer descriptors, conv padding / K-tail /
+// M-tail lanes get an out-of-range offset and the hardware returns 0, so all of a thread's 16-byte
+// loads are in flight together and have a full MFMA block to land; the steady-state loop is a single
+// basic block.  The linear block id is remapped so that the N-tiles sharing an A tile run on the
+// same XCD (private L2).
 //
 // Epilogues fuse bias / folded BatchNorm, an optional per-element addend (the loop-invariant part of
 // the GRU convolutions), activation, residual add, the GRU gate algebra (z, r*h, h = (1-z)h + z*q)
@@ -64,7 +69,7 @@ struct ConvK {
 #ifndef OFX_SCHED
 #define OFX_SCHED 2
 #endif
-constexpr int kBK = 32;
+constexpr int kKAlign = 32;   // packed weights are zero-padded along K to this (a multiple of every BK)
 
 __device__ __forceinline__ float apply_act_rt(float v, int act) {
     switch (act) {
@@ -454,7 +459,7 @@ extern "C" int ofx_conv2d_alpha(const ofx_conv_desc* d, float alpha, void* strea
     k.Hin = d->Hin; k.Win = d->Win; k.Hout = d->Hout; k.Wout = d->Wout; k.Cout = d->Cout;
     k.KW = d->KW; k.stride = d->stride; k.padH = d->padH; k.padW = d->padW;
     k.K = d->KH * d->KW * k.cin;
-    k.Kpad = ((k.K + kBK - 1) / kBK) * kBK;
+    k.Kpad = ((k.K + kKAlign - 1) / kKAlign) * kKAlign;
     const long M = (long)d->B * d->Hout * d->Wout;
     OFX_REQUIRE(M < (1L << 31) && (long)d->B * d->Hin * d->Win < (1L << 31), OFX_EINVAL);
     k.M = (int)M;
@@ -470,7 +475,7 @@ extern "C" int ofx_conv2d_alpha(const ofx_conv_desc* d, float alpha, void* strea
     const long extw = (long)d->Cout * k.Kpad * 4;
     OFX_REQUIRE(ext0 < (1L << 31) - 64 && ext1 < (1L << 31) - 64 && extw < (1L << 31) - 64, OFX_EINVAL);
     OFX_REQUIRE(k.Kpad < 65536, OFX_EINVAL);                       // umulhi division is exact in this range
-    if (d->in1) OFX_REQUIRE(d->c0 % kBK == 0, OFX_EALIGN);           // a K chunk never straddles the two segments
+    if (d->in1) OFX_REQUIRE(d->c0 % kKAlign == 0, OFX_EALIGN);           // a K chunk never straddles the two segments
     k.bytes0 = (int)ext0; k.bytes1 = (int)ext1; k.bytesw = (int)extw;
 
     switch (d->epi) {
@@ -541,7 +546,7 @@ extern "C" int ofx_conv2d_alpha(const ofx_conv_desc* d, float alpha, void* strea
 extern "C" long ofx_pack_conv_weight(const float* w, int Cout, int Cin, int KH, int KW, int cin_pad, float* out) {
     if (Cout <= 0 || Cin <= 0 || KH <= 0 || KW <= 0 || cin_pad < Cin || cin_pad % 4) return OFX_EINVAL;
     const long K = (long)KH * KW * cin_pad;
-    const long Kpad = ((K + kBK - 1) / kBK) * kBK;
+    const long Kpad = ((K + kKAlign - 1) / kKAlign) * kKAlign;
     if (!out) return Kpad;
     if (!w) return OFX_EINVAL;
     for (long i = 0; i < (long)Cout * Kpad; ++i) out[i] = 0.f;

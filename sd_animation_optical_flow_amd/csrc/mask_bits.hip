@@ -16,12 +16,11 @@ constexpr int kTW = 64;       // tile width  = one ballot
 constexpr int kTH = 32;       // tile height
 constexpr int kMaxR = 15;     // ksize <= 31
 
-enum { SRC_CONF_LT = 0, SRC_CONF_NGT = 1, SRC_EDGES = 3 };
 
 struct BitArgs {
     const float* conf;
     float* log_conf;
-    const uint8_t* image;     // SRC_EDGES: BGR image
+    const uint8_t* image;     // OFX_MSRC_EDGES: BGR image
     const uint8_t* or_mask;   // optional: out |= or_mask
     uint8_t* out;
     int H, W;
@@ -41,8 +40,8 @@ template <int SRC>
 __device__ __forceinline__ bool src_bit(const BitArgs& a, long b, int y, int x) {
     if ((unsigned)y >= (unsigned)a.H || (unsigned)x >= (unsigned)a.W) return false;
     const long pix = (b * a.H + y) * (long)a.W + x;
-    if (SRC == SRC_CONF_LT) return a.conf[pix] < a.thres;
-    if (SRC == SRC_CONF_NGT) return !(a.conf[pix] > a.thres);
+    if (SRC == OFX_MSRC_CONF_LT) return a.conf[pix] < a.thres;
+    if (SRC == OFX_MSRC_CONF_NGT) return !(a.conf[pix] > a.thres);
     // |laplacian| per channel wraps mod 256 (the reference's astype(uint8)), cv::cvtColor RGB2GRAY fixed
     // point applied to the BGR image, then > edge_thres
     const uint8_t* img = a.image + b * (long)a.H * a.W * 3;
@@ -105,7 +104,7 @@ __global__ __launch_bounds__(256) void mask_bits_kernel(const BitArgs a) {
             rows[ry * 2] = ma;
             rows[ry * 2 + 1] = mb;
         }
-        if ((SRC == SRC_CONF_LT || SRC == SRC_CONF_NGT) && a.log_conf != nullptr && ry >= r && ry < r + kTH) {
+        if ((SRC == OFX_MSRC_CONF_LT || SRC == OFX_MSRC_CONF_NGT) && a.log_conf != nullptr && ry >= r && ry < r + kTH) {
             // generate_mask's side effect: log_confidence[low] = 0 on the tile's own pixels
             if (ba && lane >= r && xa < a.W) a.log_conf[(b * a.H + y) * (long)a.W + xa] = 0.f;
             if (bb && lane < r && xb < a.W) a.log_conf[(b * a.H + y) * (long)a.W + xb] = 0.f;
@@ -171,9 +170,9 @@ int ofx_mask_bits_launch(int src, const float* conf, float* log_conf, const uint
     dim3 grid(ofx_cdiv(W, kTW), ofx_cdiv(H, kTH), B);
     OfxProfScope prof(name, s);
     switch (src) {
-        case SRC_CONF_LT: hipLaunchKernelGGL((mask_bits_kernel<SRC_CONF_LT>), grid, dim3(256), 0, s, a); break;
-        case SRC_CONF_NGT: hipLaunchKernelGGL((mask_bits_kernel<SRC_CONF_NGT>), grid, dim3(256), 0, s, a); break;
-        case SRC_EDGES: hipLaunchKernelGGL((mask_bits_kernel<SRC_EDGES>), grid, dim3(256), 0, s, a); break;
+        case OFX_MSRC_CONF_LT: hipLaunchKernelGGL((mask_bits_kernel<OFX_MSRC_CONF_LT>), grid, dim3(256), 0, s, a); break;
+        case OFX_MSRC_CONF_NGT: hipLaunchKernelGGL((mask_bits_kernel<OFX_MSRC_CONF_NGT>), grid, dim3(256), 0, s, a); break;
+        case OFX_MSRC_EDGES: hipLaunchKernelGGL((mask_bits_kernel<OFX_MSRC_EDGES>), grid, dim3(256), 0, s, a); break;
         default: return OFX_EINVAL;
     }
     return ofx_launch_status();

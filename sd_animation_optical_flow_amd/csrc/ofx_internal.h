@@ -43,6 +43,7 @@ int ofx_local_corr_launch(const float* f1, const float* f2, const float* coords,
                           float cscale, hipStream_t s);
 int ofx_corr_pool_launch(const float* l0, float* l1, float* l2, float* l3, int B, int h, int w, int levels, hipStream_t s);
 // mask_bits.hip: binary threshold/edge source -> elliptical dilation on bit planes
+enum { OFX_MSRC_CONF_LT = 0, OFX_MSRC_CONF_NGT = 1, OFX_MSRC_EDGES = 3 };   // conf < t | !(conf > t) | Laplacian edges
 int ofx_mask_bits_launch(int src, const float* conf, float* log_conf, const uint8_t* image, const uint8_t* or_mask,
                          uint8_t* out, int B, int H, int W, float thres, int edge_thres, int r, const signed char* hw,
                          const char* name, hipStream_t s);

@@ -80,7 +80,6 @@ struct ofx_raft {
     std::map<std::string, ConvW> convs;
     std::vector<void*> allocs;
     std::map<std::string, std::pair<void*, size_t>> bufs;
-    float** d_pyr_table = nullptr;
 };
 
 namespace {
@@ -528,10 +527,6 @@ int ofx_raft_create(const ofx_tensor* tensors, int n, ofx_raft** out) {
     if (!st) st = add_conv(r, sd, std::string(ub) + "flow_head.conv2", "fh2", 0, "", 1.f);
     if (!st) st = add_conv(r, sd, std::string(ub) + "mask.0", "mask0", 0, "", 1.f);
     if (!st) st = add_conv(r, sd, std::string(ub) + "mask.2", "mask2", 0, "", 0.25f);
-    if (!st) {
-        hipError_t e = hipMalloc((void**)&r->d_pyr_table, sizeof(float*) * LEVELS);
-        if (e != hipSuccess) st = (int)e;
-    }
     if (st) {
         ofx_raft_destroy(r);
         return st;
@@ -543,7 +538,6 @@ int ofx_raft_create(const ofx_tensor* tensors, int n, ofx_raft** out) {
 int ofx_raft_destroy(ofx_raft* r) {
     if (!r) return 0;
     for (void* p : r->allocs) (void)hipFree(p);
-    if (r->d_pyr_table) (void)hipFree(r->d_pyr_table);
     delete r;
     return 0;
 }

@@ -552,50 +552,15 @@ Ellipse make_ellipse(int ksize) {
 constexpr int kTileW = 64, kTileH = 16;
 constexpr int kMaxR = kMaxK / 2;
 
-enum { SRC_CONF_LT = 0, SRC_CONF_NGT = 1, SRC_U8 = 2, SRC_EDGES = 3 };
-
+// Grey-level dilation (cv2.dilate on an arbitrary uint8 image, ofgen_pdcnetplus.py:181); the binary
+// masks of generate_mask / expand_mask run on bit planes instead (mask_bits.hip).
 struct DilateArgs {
-    const float* conf;
-    float* log_conf;
-    const uint8_t* in_u8;      // SRC_U8 input, or SRC_EDGES image (BGR, 3 channels)
-    const uint8_t* or_mask;    // optional: out |= or_mask
+    const uint8_t* in_u8;
     uint8_t* out;
     int H, W;
-    float thres;
-    int edge_thres;
     Ellipse el;
 };
 
-__device__ __forceinline__ int reflect101(int i, int n) {
-    if (n == 1) return 0;
-    while (i < 0 || i >= n) i = i < 0 ? -i : 2 * n - 2 - i;
-    return i;
-}
-
-template <int SRC>
-__device__ __forceinline__ uint8_t dilate_src(const DilateArgs& a, long b, int y, int x) {
-    const long pix = (b * a.H + y) * (long)a.W + x;
-    if (SRC == SRC_CONF_LT) return a.conf[pix] < a.thres ? 255 : 0;
-    if (SRC == SRC_CONF_NGT) return a.conf[pix] > a.thres ? 0 : 255;
-    if (SRC == SRC_U8) return a.in_u8[pix];
-    // SRC_EDGES: |laplacian| per channel (wraps mod 256 like the reference's astype(uint8)),
-    // then cv::cvtColor RGB2GRAY fixed point applied to the BGR image, then > edge_thres
-    const uint8_t* img = a.in_u8 + b * (long)a.H * a.W * 3;
-    const int ym = reflect101(y - 1, a.H), yp = reflect101(y + 1, a.H);
-    const int xm = reflect101(x - 1, a.W), xp = reflect101(x + 1, a.W);
-    int g[3];
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-        const int lap = (int)img[((long)ym * a.W + x) * 3 + c] + (int)img[((long)yp * a.W + x) * 3 + c] +
-                        (int)img[((long)y * a.W + xm) * 3 + c] + (int)img[((long)y * a.W + xp) * 3 + c] -
-                        4 * (int)img[((long)y * a.W + x) * 3 + c];
-        g[c] = abs(lap) & 255;
-    }
-    const int gray = (g[0] * 9798 + g[1] * 19235 + g[2] * 3735 + (1 << 14)) >> 15;
-    return gray > a.edge_thres ? 255 : 0;
-}
-
-template <int SRC>
 __global__ __launch_bounds__(256) void dilate_kernel(const DilateArgs a) {
     __shared__ uint8_t tile[(kTileH + 2 * kMaxR) * (kTileW + 2 * kMaxR)];
     const int r = a.el.r;
@@ -606,7 +571,7 @@ __global__ __launch_bounds__(256) void dilate_kernel(const DilateArgs a) {
         const int ly = i / tw, lx = i - ly * tw;
         const int gy = y0 - r + ly, gx = x0 - r + lx;
         uint8_t v = 0;
-        if ((unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W) v = dilate_src<SRC>(a, b, gy, gx);
+        if ((unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W) v = a.in_u8[(b * a.H + gy) * (long)a.W + gx];
         tile[i] = v;
     }
     __syncthreads();
@@ -614,7 +579,7 @@ __global__ __launch_bounds__(256) void dilate_kernel(const DilateArgs a) {
     const int tx = (threadIdx.x & 15) * 4;
     const int gy = y0 + ty;
     if (gy >= a.H) return;
-    uint8_t res[4];
+    const long rowbase = (b * a.H + gy) * (long)a.W;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         int m = 0;
@@ -623,29 +588,9 @@ __global__ __launch_bounds__(256) void dilate_kernel(const DilateArgs a) {
             const uint8_t* row = &tile[(ty + r + dy) * tw + tx + j + r];
             for (int dx = -hw; dx <= hw; ++dx) m = max(m, (int)row[dx]);
         }
-        res[j] = (uint8_t)m;
-    }
-    const long rowbase = (b * a.H + gy) * (long)a.W;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
         const int gx = x0 + tx + j;
-        if (gx < a.W) {
-            uint8_t v = res[j];
-            if (a.or_mask) v |= a.or_mask[rowbase + gx];
-            a.out[rowbase + gx] = v;
-            if ((SRC == SRC_CONF_LT || SRC == SRC_CONF_NGT) && a.log_conf) {
-                if (tile[(ty + r) * tw + tx + j + r]) a.log_conf[rowbase + gx] = 0.f;
-            }
-        }
+        if (gx < a.W) a.out[rowbase + gx] = (uint8_t)m;
     }
-}
-
-template <int SRC>
-int launch_dilate(const DilateArgs& a, int B, hipStream_t s, const char* name) {
-    dim3 grid(ofx_cdiv(a.W, kTileW), ofx_cdiv(a.H, kTileH), B);
-    OfxProfScope prof(name, s);
-    hipLaunchKernelGGL((dilate_kernel<SRC>), grid, dim3(256), 0, s, a);
-    return ofx_launch_status();
 }
 
 // ------------------------------------------------------------------------------------------
@@ -782,7 +727,7 @@ int ofx_generate_mask(const float* conf, float* log_conf, uint8_t* mask, int B, 
     OFX_REQUIRE(ksize >= 1 && ksize <= kMaxK && (ksize & 1), OFX_EINVAL);
     // binary morphology runs on bit planes (mask_bits.hip)
     const Ellipse el = make_ellipse(ksize);
-    return ofx_mask_bits_launch(cmp_gt ? SRC_CONF_NGT : SRC_CONF_LT, conf, log_conf, nullptr, nullptr, mask, B, H, W, thres, 0,
+    return ofx_mask_bits_launch(cmp_gt ? OFX_MSRC_CONF_NGT : OFX_MSRC_CONF_LT, conf, log_conf, nullptr, nullptr, mask, B, H, W, thres, 0,
                                 el.r, el.hw, "generate_mask", (hipStream_t)stream);
 }
 
@@ -791,7 +736,10 @@ int ofx_dilate_u8(const uint8_t* in, uint8_t* out, int B, int H, int W, int ksiz
     OFX_REQUIRE(ksize >= 1 && ksize <= kMaxK && (ksize & 1), OFX_EINVAL);
     DilateArgs a{};
     a.in_u8 = in; a.out = out; a.H = H; a.W = W; a.el = make_ellipse(ksize);
-    return launch_dilate<SRC_U8>(a, B, (hipStream_t)stream, "dilate_u8");
+    hipStream_t s = (hipStream_t)stream;
+    OfxProfScope prof("dilate_u8", s);
+    hipLaunchKernelGGL(dilate_kernel, dim3(ofx_cdiv(W, kTileW), ofx_cdiv(H, kTileH), B), dim3(256), 0, s, a);
+    return ofx_launch_status();
 }
 
 int ofx_expand_mask(const uint8_t* mask, const uint8_t* image_bgr, uint8_t* out, uint8_t* scratch, int B, int H,
@@ -800,7 +748,7 @@ int ofx_expand_mask(const uint8_t* mask, const uint8_t* image_bgr, uint8_t* out,
     OFX_REQUIRE(mask && image_bgr && out && B > 0 && H > 0 && W > 0, OFX_EINVAL);
     OFX_REQUIRE(ksize >= 1 && ksize <= kMaxK && (ksize & 1), OFX_EINVAL);
     const Ellipse el = make_ellipse(ksize);
-    return ofx_mask_bits_launch(SRC_EDGES, nullptr, nullptr, image_bgr, mask, out, B, H, W, 0.f, edge_thres, el.r, el.hw,
+    return ofx_mask_bits_launch(OFX_MSRC_EDGES, nullptr, nullptr, image_bgr, mask, out, B, H, W, 0.f, edge_thres, el.r, el.hw,
                                 "expand_mask", (hipStream_t)stream);
 }
 

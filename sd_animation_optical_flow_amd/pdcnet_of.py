@@ -38,12 +38,13 @@ class PDCNetPlus:
     """Flow + confidence estimator with the duck type of the reference's `PDCNetPlus` (pdcnet_of.py:45-75)."""
 
     def __init__(self, ckpt_path="pre_trained_models/PDCNet_plus_m.pth.tar", device=None, iters: int = 20,
-                 confidence_sigma: float = 3.0):
+                 confidence_sigma: float = 3.0, precision: str = "fp32"):
         self.state_dict = load_checkpoint(ckpt_path)
+        self.precision = precision
         self.iters = int(iters)
         self.sigma = float(confidence_sigma)
         self.device = torch.device(device) if device is not None else torch.device("cuda")
-        self.network = RaftEngine(self.state_dict, self.device)   # like `.cuda()` at pdcnet_of.py:61
+        self.network = RaftEngine(self.state_dict, self.device, precision=precision)   # like `.cuda()` at pdcnet_of.py:61
 
     def to(self, device):
         """`pdcnet_model.to(device)` (ofgen_keyframe_inpaint.py:555).  Moving re-uploads the weights."""
@@ -54,7 +55,7 @@ class PDCNetPlus:
         new = device.index if device.index is not None else torch.cuda.current_device()
         if cur != new:
             self.device = device
-            self.network = RaftEngine(self.state_dict, device)
+            self.network = RaftEngine(self.state_dict, device, precision=self.precision)
         return self
 
     # ---- device-resident core ------------------------------------------------------------------
@@ -118,9 +119,9 @@ class PDCNetPlus:
         return flow.cpu().numpy(), conf.cpu().numpy()
 
 
-def create_of_algo(ckpt) -> PDCNetPlus:
-    """pdcnet_of.py:77-79."""
-    return PDCNetPlus(ckpt)
+def create_of_algo(ckpt, precision: str = "fp32") -> PDCNetPlus:
+    """pdcnet_of.py:77-79.  `precision` is an extension (default: the reference's fp32 arithmetic)."""
+    return PDCNetPlus(ckpt, precision=precision)
 
 
 # --------------------------------------------------------------------------------------------------
