@@ -49,7 +49,10 @@ const char* ofx_error_string(int code);
 /* ---------------------------------------------------------------- profiling (HIP events) */
 /* When enabled, every kernel launch issued through this library is bracketed by a pair of
  * hipEvents recorded on the launch stream.  ofx_prof_collect synchronises, accumulates the elapsed
- * times per kernel name and writes a JSON object {"name": {"calls": n, "ms": total}, ...}. */
+ * times per kernel name and writes a JSON object {"name": {"calls": n, "ms": total, "flops": executed}, ...}
+ * ("flops" is non-zero for the GEMM/conv launches).
+ * on = 1: one entry per kernel family; on = 2: the RAFT executor's convolutions are split per layer
+ * ("family:layer"). */
 int ofx_prof_enable(int on);
 int ofx_prof_collect(char* json_out, size_t cap);
 

@@ -37,6 +37,9 @@
 // and the flow/coords update, so none of those run as separate passes.
 #include "ofx_internal.h"
 
+#include <algorithm>
+#include <type_traits>
+
 namespace {
 
 struct ConvK {
@@ -81,7 +84,7 @@ __device__ __forceinline__ float apply_act_rt(float v, int act) {
 }
 
 template <int BM, int BN, int WM, int WN, int EPI, bool NORM, int BK, int PREC>
-__global__ __launch_bounds__(256) void igemm_kernel(const ConvK p) {
+__global__ __launch_bounds__(256, (BK == 16 && PREC == 0) ? 3 : 1) void igemm_kernel(const ConvK p) {
     constexpr int TM = WM / 32, TN = WN / 32;
     constexpr int WAVES_N = BN / WN;
     constexpr int LDK = BK + 4;               // LDS row stride in floats (144 B / 80 B): conflict-free b128 fragment reads
@@ -358,54 +361,118 @@ __global__ __launch_bounds__(256) void igemm_kernel(const ConvK p) {
 #endif
     }
 
-    // ---- epilogue.  C/D layout of the 32x32 MFMA: col (n) = lane&31, row (m) = (e&3) + 8*(e>>2) + 4*(lane>>5)
+    // ---- epilogue.  C/D layout of the 32x32 MFMA: col (n) = lane&31, row (m) = (e&3) + 8*(e>>2) + 4*(lane>>5).
+    // Each 32x32 sub-tile runs in two phases -- every global read it needs (addend, residual, z, h) is
+    // issued first, then the arithmetic and the stores.  The epilogue reads and writes the same buffers (h
+    // is updated in place), so a naive element loop keeps each load behind the previous element's store and
+    // turns the 64 elements of a thread into 64 serial memory round trips.  All accesses go through buffer
+    // descriptors: one VGPR byte offset per array (the thread's first row and column), the row step as a
+    // scalar offset, and the ragged last M / N tile handled by the hardware range check (offset | kOOB).
     float* __restrict__ out = p.out ? p.out + (long)z * p.o_zs : nullptr;
+    const int Mrows = p.M;
+    auto rsrc_of = [&](const void* ptr, int ld) {
+        const long bytes = ptr ? (long)Mrows * ld * 4 : 0;
+        return __builtin_amdgcn_make_buffer_rsrc((void*)ptr, (short)0, (int)bytes, 0x00020000);
+    };
+    auto ldf = [](__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+        return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+    };
+    auto stf = [](float v, __amdgpu_buffer_rsrc_t r, int voff, int soff) {
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r, voff, soff, 0);
+    };
+    const bool has_add = p.addend != nullptr;
+    const bool has_res = p.res != nullptr;
+    const int mb0 = m0 + wm * WM + 4 * (lane >> 5);       // first row of this thread
+    const int lim = Mrows - mb0;                          // relative rows r < lim exist
+    constexpr int EB = EPI == OFX_EPI_GRU_Q ? 4 : 8;
+    auto epilogue = [&](auto full_tag) {
+        constexpr bool FULL = decltype(full_tag)::value;  // tile entirely inside M: no per-row masks
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int n = n0 + wn * WN + j * 32 + (lane & 31);
-        if (n >= p.Cout) continue;
-        const float sc = p.scale ? p.scale[n] * p.alpha : p.alpha;
-        const float sh = p.shift ? p.shift[n] : 0.0f;
+        for (int j = 0; j < TN; ++j) {
+            const int nbase = n0 + wn * WN + j * 32;      // wave-uniform
+            const int n = nbase + (lane & 31);
+            const bool nok = n < p.Cout;
+            const int nn = min(n, p.Cout - 1);
+            const int cmask = nok ? 0 : kOOB;
+            const float sc = p.scale ? p.scale[nn] * p.alpha : p.alpha;
+            const float sh = p.shift ? p.shift[nn] : 0.0f;
+            if constexpr (EPI == OFX_EPI_FLOW) {
+                // Cout = 2: a handful of lanes; plain pointer code
 #pragma unroll
-        for (int i = 0; i < TM; ++i) {
+                for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int m = m0 + wm * WM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
-                if (m >= p.M) continue;
-                float v = acc[i][j][e] * sc + sh;
-                if (p.addend) v += p.addend[(long)m * p.ldadd + n];
-                if (EPI == OFX_EPI_PLAIN) {
-                    v = apply_act_rt(v, p.act);
-                    if (p.res) v = fmaxf(v + p.res[(long)m * p.ldres + n], 0.f);
-                    out[(long)m * p.ldo + n] = v;
-                } else if (EPI == OFX_EPI_GRU_ZR) {
-                    const int hd = p.Cout >> 1;
-                    v = ofx_sigmoid(v);
-                    if (n < hd) {
-                        p.aux_z[(long)m * hd + n] = v;
-                    } else {
-                        const int c = n - hd;
-                        p.aux_rh[(long)m * hd + c] = v * p.aux_h[(long)m * p.ldh + c];
+                    for (int e = 0; e < 16; ++e) {
+                        const int m = mb0 + i * 32 + (e & 3) + 8 * (e >> 2);
+                        if (!nok || m >= Mrows) continue;
+                        float v = acc[i][j][e] * sc + sh;
+                        if (has_add) v += p.addend[(long)m * p.ldadd + n];
+                        const int rem = m % HWo;
+                        const int oy = rem / p.Wout;
+                        const int ox = rem - oy * p.Wout;
+                        const float c1 = p.aux_coords[(long)m * 2 + n] + v;
+                        p.aux_coords[(long)m * 2 + n] = c1;
+                        const float fl = c1 - (float)(n == 0 ? ox : oy);
+                        p.aux_h[(long)m * p.ldh + n] = fl;
+                        p.aux_flow4[(long)m * 4 + n] = fl;
                     }
-                } else if (EPI == OFX_EPI_GRU_Q) {
-                    const float qv = ofx_tanh(v);
-                    const float zz = p.aux_z[(long)m * p.Cout + n];
-                    const long hi = (long)m * p.ldh + n;
-                    const float h = p.aux_h[hi];
-                    p.aux_h[hi] = (1.0f - zz) * h + zz * qv;
-                } else if (EPI == OFX_EPI_FLOW) {
-                    const int rem = m % HWo;
-                    const int oy = rem / p.Wout;
-                    const int ox = rem - oy * p.Wout;
-                    const float c1 = p.aux_coords[(long)m * 2 + n] + v;
-                    p.aux_coords[(long)m * 2 + n] = c1;
-                    const float fl = c1 - (float)(n == 0 ? ox : oy);
-                    p.aux_h[(long)m * p.ldh + n] = fl;
-                    p.aux_flow4[(long)m * 4 + n] = fl;
+            } else {
+                const int hd = p.Cout >> 1;
+                // the z | r split of the fused GRU gate conv is 32-aligned -> uniform per wave and j
+                const bool r_half = EPI == OFX_EPI_GRU_ZR && __builtin_amdgcn_readfirstlane(nbase) >= hd;
+                const __amdgpu_buffer_rsrc_t rs_add = rsrc_of(p.addend, p.ldadd);
+                const int vo_add = ((mb0 * p.ldadd + n) * 4) | cmask;
+                // array 1 / array 2 read by this epilogue, array written
+                const void* p1 = EPI == OFX_EPI_PLAIN ? (const void*)p.res : EPI == OFX_EPI_GRU_ZR ? (const void*)p.aux_h : (const void*)p.aux_z;
+                const int ld1 = EPI == OFX_EPI_PLAIN ? p.ldres : EPI == OFX_EPI_GRU_ZR ? p.ldh : p.Cout;
+                const int c1 = EPI == OFX_EPI_GRU_ZR ? n - hd : n;
+                const __amdgpu_buffer_rsrc_t rs_1 = rsrc_of(p1, ld1);
+                const int vo_1 = ((mb0 * ld1 + c1) * 4) | cmask;
+                const __amdgpu_buffer_rsrc_t rs_h = rsrc_of(p.aux_h, p.ldh);          // GRU_Q: h read and written
+                const int vo_h = ((mb0 * p.ldh + n) * 4) | cmask;
+                const void* pw = EPI == OFX_EPI_PLAIN ? (void*)out : EPI == OFX_EPI_GRU_Q ? (void*)p.aux_h : r_half ? (void*)p.aux_rh : (void*)p.aux_z;
+                const int ldw = EPI == OFX_EPI_PLAIN ? p.ldo : EPI == OFX_EPI_GRU_Q ? p.ldh : hd;
+                const int cw = (EPI == OFX_EPI_GRU_ZR && r_half) ? n - hd : n;
+                const __amdgpu_buffer_rsrc_t rs_w = rsrc_of(pw, ldw);
+                const int vo_w = ((mb0 * ldw + cw) * 4) | cmask;
+                const bool need1 = EPI == OFX_EPI_PLAIN ? has_res : EPI == OFX_EPI_GRU_ZR ? r_half : true;
+#pragma unroll
+                for (int ib = 0; ib < TM * (16 / EB); ++ib) {
+                    // EB elements per phase: enough loads in flight to cover the latency, few enough live
+                    // registers to keep the kernel at three workgroups per CU
+                    const int i = ib / (16 / EB), e0 = (ib % (16 / EB)) * EB;
+                    float ad[EB], x1[EB], x2[EB];
+#pragma unroll
+                    for (int q = 0; q < EB; ++q) {
+                        const int e = e0 + q;
+                        const int r = i * 32 + (e & 3) + 8 * (e >> 2);
+                        const int rmask = FULL ? 0 : (r < lim ? 0 : kOOB);
+                        ad[q] = has_add ? ldf(rs_add, vo_add | rmask, r * p.ldadd * 4) : 0.0f;
+                        x1[q] = need1 ? ldf(rs_1, vo_1 | rmask, r * ld1 * 4) : 0.0f;
+                        x2[q] = EPI == OFX_EPI_GRU_Q ? ldf(rs_h, vo_h | rmask, r * p.ldh * 4) : 0.0f;
+                    }
+#pragma unroll
+                    for (int q = 0; q < EB; ++q) {
+                        const int e = e0 + q;
+                        const int r = i * 32 + (e & 3) + 8 * (e >> 2);
+                        const int rmask = FULL ? 0 : (r < lim ? 0 : kOOB);
+                        float v = acc[i][j][e] * sc + sh + ad[q];
+                        if (EPI == OFX_EPI_PLAIN) {
+                            v = apply_act_rt(v, p.act);
+                            if (has_res) v = fmaxf(v + x1[q], 0.f);
+                        } else if (EPI == OFX_EPI_GRU_ZR) {
+                            v = ofx_sigmoid(v);
+                            if (r_half) v *= x1[q];
+                        } else {
+                            v = (1.0f - x1[q]) * x2[q] + x1[q] * ofx_tanh(v);
+                        }
+                        stf(v, rs_w, vo_w | rmask, r * ldw * 4);
+                    }
                 }
             }
         }
-    }
+    };
+    if (m0 + BM <= Mrows) epilogue(std::true_type{});
+    else epilogue(std::false_type{});
 }
 
 template <int BM, int BN, int WM, int WN, int BK, int PREC = 0>
@@ -447,6 +514,37 @@ extern "C" int ofx_conv2d_alpha(const ofx_conv_desc* d, float alpha, void* strea
     }
     if (d->addend) OFX_REQUIRE(d->ldadd >= d->Cout, OFX_EINVAL);
     const int nz = d->nz > 1 ? d->nz : 1;
+    {
+        // The epilogue addresses out / res / addend / aux_* with 32-bit byte offsets (descriptor extent
+        // M * ld * 4).  A pure GEMM (1x1, stride 1, no padding, plain epilogue -- the correlation volume of a
+        // large frame is the case that gets here) is split along M; anything else must be sliced by the caller.
+        int ld_epi = std::max(d->Cout, d->out ? d->ldo : 0);
+        if (d->res) ld_epi = std::max(ld_epi, d->ldres);
+        if (d->addend) ld_epi = std::max(ld_epi, d->ldadd);
+        if (d->aux_h) ld_epi = std::max(ld_epi, d->ldh);
+        const long Mtot = (long)d->B * d->Hout * d->Wout;
+        const long lim = (1L << 31) - 64;
+        if (Mtot * ld_epi * 4 >= lim) {
+            const bool gemm = d->KH == 1 && d->KW == 1 && d->stride == 1 && d->padH == 0 && d->padW == 0 &&
+                              d->epi == OFX_EPI_PLAIN && !d->nmean && d->Hout == d->Hin && d->Wout == d->Win;
+            OFX_REQUIRE(gemm, OFX_EINVAL);
+            const long rows = std::max<long>(128, ((lim / ((long)ld_epi * 4)) / 128 - 1) * 128);
+            OFX_REQUIRE(rows * ld_epi * 4 < lim, OFX_EINVAL);
+            for (long r0 = 0; r0 < Mtot; r0 += rows) {
+                ofx_conv_desc part = *d;
+                const long n = std::min(rows, Mtot - r0);
+                part.B = 1; part.Hin = part.Hout = 1; part.Win = part.Wout = (int)n;
+                part.in0 = d->in0 + r0 * d->ld0;
+                if (d->in1) part.in1 = d->in1 + r0 * d->ld1;
+                part.out = d->out + r0 * d->ldo;
+                if (d->res) part.res = d->res + r0 * d->ldres;
+                if (d->addend) part.addend = d->addend + r0 * d->ldadd;
+                const int st = ofx_conv2d_alpha(&part, alpha, stream);
+                if (st) return st;
+            }
+            return 0;
+        }
+    }
 
     ConvK k;
     k.in0 = d->in0; k.in1 = d->in1; k.w = d->w; k.scale = d->scale; k.shift = d->shift; k.addend = d->addend;
@@ -522,6 +620,7 @@ extern "C" int ofx_conv2d_alpha(const ofx_conv_desc* d, float alpha, void* strea
                        : d->epi == OFX_EPI_FLOW   ? "igemm_conv_flow"
                                                   : "igemm_conv";
     OfxProfScope prof(pname, s);
+    prof.flops(2.0 * (double)M * d->Cout * k.K * nz);
     // BK = 16 keeps LDS at 41 KB and registers under 168 for the 128x128 tile -> 3 workgroups per CU; the
     // extra resident wave per SIMD hides the commit/barrier/issue phases better than a longer chunk does
     // (measured +4..10 % on every shape).  tile = BK*1e6 + BM*1e3 + BN overrides.

@@ -22,11 +22,14 @@ static inline int ofx_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 // ---- profiling hooks (prof.cpp) -------------------------------------------------------
 // Usage in a launcher:   OfxProfScope _p("kernel_name", stream);  kernel<<<...>>>(...);
 // The scope records an event pair on `stream` when profiling is enabled and is free otherwise.
+// ofx_prof_enable(2): launches are accumulated per "family:tag"; the RAFT executor tags each layer.
+void ofx_prof_set_tag(const char* tag);   // thread-local; the pointer must outlive the launches it labels
 struct OfxProfScope {
     int slot;
     hipStream_t stream;
     OfxProfScope(const char* name, hipStream_t s);
     ~OfxProfScope();
+    void flops(double f);   // executed FLOPs of the bracketed launch (reported by ofx_prof_collect)
 };
 
 static inline int ofx_launch_status() {

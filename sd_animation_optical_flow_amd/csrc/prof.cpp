@@ -16,9 +16,11 @@ namespace {
 struct Rec {
     int name_id;
     hipEvent_t a, b;
+    double flops;
 };
 std::mutex g_mu;
-bool g_on = false;
+int g_on = 0;                          // 0 off, 1 per kernel family, 2 per layer (family:tag)
+thread_local const char* g_tag = nullptr;
 std::vector<std::string> g_names;
 std::map<std::string, int> g_name_ids;
 std::vector<Rec> g_recs;
@@ -40,16 +42,19 @@ OfxProfScope::OfxProfScope(const char* name, hipStream_t s) : slot(-1), stream(s
     if (!g_on) return;
     std::lock_guard<std::mutex> lk(g_mu);
     int id;
-    auto it = g_name_ids.find(name);
+    std::string key(name);
+    if (g_on == 2 && g_tag) key.append(":").append(g_tag);
+    auto it = g_name_ids.find(key);
     if (it == g_name_ids.end()) {
         id = (int)g_names.size();
-        g_names.push_back(name);
-        g_name_ids[name] = id;
+        g_names.push_back(key);
+        g_name_ids[key] = id;
     } else {
         id = it->second;
     }
     Rec r;
     r.name_id = id;
+    r.flops = 0.0;
     r.a = get_event();
     r.b = get_event();
     if (!r.a || !r.b) return;
@@ -63,6 +68,14 @@ OfxProfScope::~OfxProfScope() {
     std::lock_guard<std::mutex> lk(g_mu);
     (void)hipEventRecord(g_recs[slot].b, stream);
 }
+
+void OfxProfScope::flops(double f) {
+    if (slot < 0) return;
+    std::lock_guard<std::mutex> lk(g_mu);
+    g_recs[slot].flops = f;
+}
+
+void ofx_prof_set_tag(const char* tag) { g_tag = tag; }
 
 extern "C" {
 
@@ -84,7 +97,7 @@ const char* ofx_error_string(int code) {
 
 int ofx_prof_enable(int on) {
     std::lock_guard<std::mutex> lk(g_mu);
-    g_on = on != 0;
+    g_on = on < 0 ? 0 : (on > 2 ? 2 : on);
     return 0;
 }
 
@@ -94,11 +107,13 @@ int ofx_prof_collect(char* json_out, size_t cap) {
     std::lock_guard<std::mutex> lk(g_mu);
     std::vector<double> ms(g_names.size(), 0.0);
     std::vector<long> calls(g_names.size(), 0);
+    std::vector<double> flops(g_names.size(), 0.0);
     for (auto& r : g_recs) {
         float t = 0.f;
         if (hipEventElapsedTime(&t, r.a, r.b) == hipSuccess) {
             ms[r.name_id] += t;
             calls[r.name_id] += 1;
+            flops[r.name_id] += r.flops;
         }
         g_pool.push_back(r.a);
         g_pool.push_back(r.b);
@@ -109,8 +124,8 @@ int ofx_prof_collect(char* json_out, size_t cap) {
     for (size_t i = 0; i < g_names.size(); ++i) {
         if (!calls[i]) continue;
         char buf[256];
-        snprintf(buf, sizeof buf, "%s\"%s\": {\"calls\": %ld, \"ms\": %.6f}", first ? "" : ", ",
-                 g_names[i].c_str(), calls[i], ms[i]);
+        snprintf(buf, sizeof buf, "%s\"%s\": {\"calls\": %ld, \"ms\": %.6f, \"flops\": %.6e}", first ? "" : ", ",
+                 g_names[i].c_str(), calls[i], ms[i], flops[i]);
         s += buf;
         first = false;
     }

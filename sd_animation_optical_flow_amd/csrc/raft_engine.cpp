@@ -19,6 +19,7 @@
 // and broadcast through a zero batch stride of the correlation GEMM.
 #include "ofx_internal.h"
 
+#include <algorithm>
 #include <cmath>
 #include <cstring>
 #include <map>
@@ -33,6 +34,7 @@ struct ConvW {
     float* shift = nullptr;   // [Cout] or null
     int cout = 0, cin = 0, cin_pad = 0, kh = 0, kw = 0;
     long kpad = 0;
+    std::string name;         // layer label for the per-layer profile (ofx_prof_enable(2))
 };
 
 struct HostTensor {
@@ -61,6 +63,13 @@ constexpr int FLOW_OFF = MOT_OFF + 126;
 constexpr int INP_OFF = HD + 128;
 constexpr int GADD_LD = 2 * (2 * HD + HD);   // [zr1(256) | q1(128) | zr2(256) | q2(128)]
 constexpr int ENC_CHUNK = 16;          // images per encoder pass (bounds the activation workspace)
+// ... fewer for large frames: the widest encoder activation (64 channels at half resolution) must stay
+// below the 2 GiB reach of the convolution kernel's 32-bit byte offsets
+static inline int enc_chunk(int H, int W) {
+    const long per_image = (long)(H / 2) * (W / 2) * 64 * 4;
+    const long fit = ((1L << 31) - 4096) / per_image;
+    return (int)std::max<long>(1, std::min<long>(ENC_CHUNK, fit));
+}
 
 struct Carver {
     char* base;
@@ -165,6 +174,7 @@ int add_conv(ofx_raft* r, const std::map<std::string, HostTensor>& sd, const std
         append_w->insert(append_w->end(), pw.begin(), pw.end());
         append_shift->insert(append_shift->end(), shift.begin(), shift.end());
         c.w = nullptr;
+        c.name = store_as;
         r->convs[store_as] = c;
         return 0;
     }
@@ -176,6 +186,7 @@ int add_conv(ofx_raft* r, const std::map<std::string, HostTensor>& sd, const std
         st = upload(r, scale, &c.scale);
         if (st) return st;
     }
+    c.name = store_as;
     r->convs[store_as] = c;
     return 0;
 }
@@ -228,6 +239,7 @@ int build_gru(ofx_raft* r, const std::map<std::string, HostTensor>& sd, const st
             st = upload(r, sh, &c.shift);
             if (st) return st;
         }
+        c.name = "gru.zr" + tag + sfx;
         r->convs["gru.zr" + tag + sfx] = c;
         st = add_conv(r, sd, "update_block.gru.convq" + tag, "gru.q" + tag + sfx, 0, "", 1.f, nullptr, nullptr, sel, bias);
         if (st) return st;
@@ -270,7 +282,9 @@ struct Launcher {
         d.act = act; d.epi = epi;
         d.precision = precision;
         if (c0 + c1 != c.cin_pad) { st = OFX_EKEY; return; }
+        ofx_prof_set_tag(c.name.c_str());
         st = ofx_conv2d(&d, s);
+        ofx_prof_set_tag(nullptr);
     }
 };
 
@@ -378,7 +392,7 @@ static RaftWs carve(void* base, size_t cap, int B, int H, int W, int flags, int 
     const long N = (long)h * wd;
     const long M = (long)B * N;
     const int most = n_images > 0 ? n_images : 2 * B;
-    const int nch = ENC_CHUNK < most ? ENC_CHUNK : most;
+    const int nch = std::min(enc_chunk(H, W), most);
     const long half = (long)(H / 2) * (W / 2) * 64;
     w.eb.x0 = c.take((size_t)nch * H * W * 4);
     w.eb.X = c.take((size_t)nch * half);
@@ -571,13 +585,13 @@ int ofx_raft_forward(ofx_raft* r, const uint8_t* image1, const uint8_t* image2, 
     // ---- feature encoders (instance norm => per-image statistics, so chunking is exact)
     int st = 0;
     const int n1 = sh1 ? 1 : B, n2 = sh2 ? 1 : B;
-    for (int i0 = 0; i0 < n1 && !st; i0 += ENC_CHUNK) {
-        const int n = std::min(ENC_CHUNK, n1 - i0);
+    for (int i0 = 0; i0 < n1 && !st; i0 += enc_chunk(H, W)) {
+        const int n = std::min(enc_chunk(H, W), n1 - i0);
         st = run_encoder(r, "fnet", false, image1 + i0 * img_bytes, n, H, W, bgr, ws.eb, ws.fmap1 + (long)i0 * N * FD, FD,
                          false, 0, s, prec);
     }
-    for (int i0 = 0; i0 < n2 && !st; i0 += ENC_CHUNK) {
-        const int n = std::min(ENC_CHUNK, n2 - i0);
+    for (int i0 = 0; i0 < n2 && !st; i0 += enc_chunk(H, W)) {
+        const int n = std::min(enc_chunk(H, W), n2 - i0);
         st = run_encoder(r, "fnet", false, image2 + i0 * img_bytes, n, H, W, bgr, ws.eb, ws.fmap2 + (long)i0 * N * FD, FD,
                          false, 0, s, prec);
     }
@@ -588,8 +602,8 @@ int ofx_raft_forward(ofx_raft* r, const uint8_t* image1, const uint8_t* image2, 
             OFX_HIP_CHECK(hipMemcpyAsync(ws.hx + (long)k * N * HX_LD, ws.hx, (size_t)N * HX_LD * sizeof(float),
                                          hipMemcpyDeviceToDevice, s));
     } else {
-        for (int i0 = 0; i0 < B && !st; i0 += ENC_CHUNK) {
-            const int n = std::min(ENC_CHUNK, B - i0);
+        for (int i0 = 0; i0 < B && !st; i0 += enc_chunk(H, W)) {
+            const int n = std::min(enc_chunk(H, W), B - i0);
             st = run_encoder(r, "cnet", true, image1 + i0 * img_bytes, n, H, W, bgr, ws.eb, ws.hx + (long)i0 * N * HX_LD,
                              HX_LD, true, INP_OFF, s, prec);
         }
@@ -663,8 +677,8 @@ int ofx_raft_forward_pairs(ofx_raft* r, const uint8_t* images, int n_images, con
     int st = 0;
     // every image is encoded ONCE (feature + context), however many pairs it takes part in: a 15-frame
     // KeyframeConv window has 210 ordered pairs but only 15 images (ofgen_keyframe_inpaint.py:627-668)
-    for (int i0 = 0; i0 < n_images && !st; i0 += ENC_CHUNK) {
-        const int n = std::min(ENC_CHUNK, n_images - i0);
+    for (int i0 = 0; i0 < n_images && !st; i0 += enc_chunk(H, W)) {
+        const int n = std::min(enc_chunk(H, W), n_images - i0);
         st = run_encoder(r, "fnet", false, images + i0 * img_bytes, n, H, W, bgr, ws.eb, ws.fmap1 + (long)i0 * N * FD, FD, false,
                          0, s, prec);
         if (!st)

@@ -44,12 +44,13 @@ def _ptr(t: Optional[torch.Tensor]) -> C.c_void_p:
 # --------------------------------------------------------------------------------------
 # profiling
 # --------------------------------------------------------------------------------------
-def prof_enable(on: bool) -> None:
-    check(_lib.lib().ofx_prof_enable(1 if on else 0), "ofx_prof_enable")
+def prof_enable(on) -> None:
+    """False/0: off; True/1: per kernel family; 2: per layer of the RAFT executor ("family:layer")."""
+    check(_lib.lib().ofx_prof_enable(int(on)), "ofx_prof_enable")
 
 
 def prof_collect() -> dict:
-    buf = C.create_string_buffer(1 << 16)
+    buf = C.create_string_buffer(1 << 18)
     check(_lib.lib().ofx_prof_collect(buf, len(buf)), "ofx_prof_collect")
     return json.loads(buf.value.decode())
 

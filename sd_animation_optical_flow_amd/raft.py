@@ -117,10 +117,10 @@ class RaftEngine:
             flags |= FLAG_SHARED_IMG2
         if alternate_corr:
             flags |= FLAG_ALT_CORR
-        # the conv kernels address their inputs with 32-bit byte offsets (buffer descriptors): the widest
-        # input (the 384-channel GRU state row) must stay below 2 GiB -> larger batches are processed in
-        # slices (pairs are independent)
-        max_pairs = max(1, ((1 << 31) - 4096) // ((H // 8) * (W // 8) * 384 * 4))
+        # the conv kernels address their operands with 32-bit byte offsets (buffer descriptors): the widest
+        # array (the 768-float row of the hoisted GRU context term) must stay below 2 GiB -> larger batches
+        # are processed in slices (pairs are independent)
+        max_pairs = max(1, ((1 << 31) - 4096) // ((H // 8) * (W // 8) * 768 * 4))
         if B > max_pairs:
             ups, lows = [], []
             for b0 in range(0, B, max_pairs):

@@ -422,3 +422,22 @@ def test_warp_and_mask_full_size_properties(cuda):
     raw = (conf < 0.5).to(torch.uint8) * 255
     assert bool((m1 >= raw).all()) and bool((m2 >= m1).all())
     assert set(torch.unique(m1).tolist()) <= {0, 255}
+
+
+def test_corr_volume_beyond_2gib_is_split_along_m(cuda):
+    """A 1280x1280 frame: the level-0 volume of ONE pair is 25600^2 floats = 2.6 GB, past the 2 GiB reach of
+    the GEMM epilogue's 32-bit offsets -> the launcher splits it along M.  Rows either side of the split
+    boundary (20736) against an f64 matmul; level 1 against the pooled reference."""
+    ops = _ops()
+    h = w = 160
+    g = torch.Generator().manual_seed(15)
+    f1 = torch.randn((1, h, w, 256), generator=g).cuda()
+    f2 = torch.randn((1, h, w, 256), generator=g).cuda()
+    pyr = ops.corr_volume(f1, f2)
+    rows = torch.tensor([0, 1, 12345, 20735, 20736, 20737, 25599], device="cuda")
+    ref = (f1.view(-1, 256)[rows].double() @ f2.view(-1, 256).double().T / 16.0).float()
+    got = pyr[0].view(h * w, h * w)[rows]
+    assert (got - ref).abs().max().item() < 3e-5
+    ref1 = torch.nn.functional.avg_pool2d(ref.view(len(rows), 1, h, w), 2)[:, 0]
+    assert (pyr[1][rows] - ref1).abs().max().item() < 3e-5
+    assert torch.isfinite(pyr[3]).all()

@@ -218,3 +218,22 @@ def test_large_frame_1024x1024_single_pair(cuda, raft_sd):
     assert tuple(up.shape) == (1, H, W, 2) and torch.isfinite(up).all()
     # the convex upsample of a constant field is the constant field x 8: check on the coarse flow's interior mean
     assert abs(float(up[0, 64:-64, 64:-64].mean()) / max(abs(float(lo[0, 8:-8, 8:-8].mean())), 1e-6) - 8.0) < 1.0
+
+
+def test_full_hd_frame_single_pair(cuda, raft_sd):
+    """1920x1080 (1/8 grid 135x240, odd height): the volume GEMM's M split engages (32400^2 floats = 4.2 GB);
+    the level-0 volume must agree with a direct evaluation from the engine's own feature maps."""
+    from sd_animation_optical_flow_amd.raft import RaftEngine
+    eng = RaftEngine(raft_sd)
+    g = torch.Generator(device="cuda").manual_seed(3)
+    a = torch.randint(0, 256, (1080, 1920, 3), dtype=torch.uint8, device="cuda", generator=g)
+    b = torch.randint(0, 256, (1080, 1920, 3), dtype=torch.uint8, device="cuda", generator=g)
+    up = eng.forward(a[None], b[None], iters=2)
+    assert tuple(up.shape) == (1, 1080, 1920, 2) and bool(torch.isfinite(up).all())
+    N = 135 * 240
+    f1 = eng.buffer("fmap1").view(N, 256)
+    f2 = eng.buffer("fmap2").view(N, 256)
+    rows = torch.tensor([0, 777, 16383, 16384, N - 1], device="cuda")
+    ref = (f1[rows].double() @ f2.double().T / 16.0).float()
+    got = eng.buffer("pyr0").view(N, N)[rows]
+    assert (got - ref).abs().max().item() < 1e-4 * max(1.0, ref.abs().max().item())
