@@ -84,7 +84,7 @@ __device__ __forceinline__ float apply_act_rt(float v, int act) {
 }
 
 template <int BM, int BN, int WM, int WN, int EPI, bool NORM, int BK, int PREC>
-__global__ __launch_bounds__(256, (BK == 16 && PREC == 0) ? 3 : 1) void igemm_kernel(const ConvK p) {
+__global__ __launch_bounds__(256, BK == 16 ? 3 : 1) void igemm_kernel(const ConvK p) {
     constexpr int TM = WM / 32, TN = WN / 32;
     constexpr int WAVES_N = BN / WN;
     constexpr int LDK = BK + 4;               // LDS row stride in floats (144 B / 80 B): conflict-free b128 fragment reads
