@@ -1,8 +1,8 @@
 // Flow-head output convolution: 3x3, 256 -> 2 channels, fused with coords1 += delta (RAFT/core/update.py:6-14,
 // RAFT/core/raft.py:131).  With two output channels the implicit-GEMM kernel runs its smallest tile at 1/16
 // utilisation (2.7 % of the step); here each lane owns four input channels of all nine taps and keeps its
-// 72 weights in registers, a wavefront walks over pixels, and the two dot products are reduced with
-// cross-lane adds.  Input rows are re-read from L1/L2 by the 3x3 window; HBM sees every byte once.
+// 72 weights in registers, a wavefront walks over strips of adjacent pixels, and the dot products are reduced
+// with cross-lane adds.  HBM sees every input byte once.
 #include "ofx_internal.h"
 
 namespace {
@@ -17,44 +17,110 @@ struct FlowHeadArgs {
     int ldx, ldh, Kpad, h, w_, M;
 };
 
-__global__ __launch_bounds__(256) void flow_head_kernel(const FlowHeadArgs a) {
+constexpr int kPW = 8;   // output pixels per wavefront strip
+
+// One wavefront produces a strip of kPW horizontally adjacent pixels: the 3 x (kPW+2) input rows it needs
+// are each loaded once (3.75 row reads per output pixel instead of 9) and every loaded row feeds the three
+// horizontal taps it belongs to.  Lane l owns input channels 4l..4l+3 of all nine taps and both outputs
+// (72 weights in registers); the 2*kPW partial sums are reduced across the 64 lanes with a transposing
+// butterfly (17 cross-lane exchanges per strip instead of 6 per value).
+__global__ __launch_bounds__(256, 3) void flow_head_kernel(const FlowHeadArgs a) {
     const int lane = threadIdx.x & 63;
     const int gw = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;      // global wave id
     const int nw = (gridDim.x * blockDim.x) >> 6;
-    // lane l owns input channels 4l..4l+3 for all 9 taps and both outputs: 72 weights in registers
     float4 w0[9], w1[9];
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
         w0[t] = *reinterpret_cast<const float4*>(a.w + t * 256 + lane * 4);
         w1[t] = *reinterpret_cast<const float4*>(a.w + a.Kpad + t * 256 + lane * 4);
     }
-    const float b0 = a.bias[0], b1 = a.bias[1];
-    const int hw = a.h * a.w_;
-    for (int m = gw; m < a.M; m += nw) {
-        const int rem = m % hw;
-        const int y = rem / a.w_, x = rem - y * a.w_;
-        float s0 = 0.f, s1 = 0.f;
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, (short)0, a.M * a.ldx * 4, 0x00020000);
+    const int spr = (a.w_ + kPW - 1) / kPW;          // strips per image row
+    const int nstrips = (a.M / a.w_) * spr;          // M = B*h*w
+    for (int sidx = gw; sidx < nstrips; sidx += nw) {
+        const int row = sidx / spr;                  // b*h + y
+        const int x0 = (sidx - row * spr) * kPW;
+        const int y = row % a.h;
+        float acc[2 * kPW];
 #pragma unroll
-        for (int t = 0; t < 9; ++t) {
-            const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
-            if ((unsigned)yy < (unsigned)a.h && (unsigned)xx < (unsigned)a.w_) {     // wave-uniform
-                const float4 v = *reinterpret_cast<const float4*>(a.x + (long)(m + (t / 3 - 1) * a.w_ + (t % 3 - 1)) * a.ldx + lane * 4);
-                s0 = fmaf(v.x, w0[t].x, s0); s0 = fmaf(v.y, w0[t].y, s0); s0 = fmaf(v.z, w0[t].z, s0); s0 = fmaf(v.w, w0[t].w, s0);
-                s1 = fmaf(v.x, w1[t].x, s1); s1 = fmaf(v.y, w1[t].y, s1); s1 = fmaf(v.z, w1[t].z, s1); s1 = fmaf(v.w, w1[t].w, s1);
+        for (int i = 0; i < 2 * kPW; ++i) acc[i] = 0.f;
+        // rows are read through a buffer descriptor: one VGPR offset (lane * 16), the pixel as a scalar
+        // offset, out-of-image taps as an out-of-range offset (the hardware returns 0)
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const bool yin = (unsigned)(y + ky - 1) < (unsigned)a.h;                       // wave-uniform
+            const int pix0 = (row + ky - 1) * a.w_ + x0 - 1;
+            float4 v[kPW + 2];
+#pragma unroll
+            for (int c = 0; c < kPW + 2; ++c) {
+                const bool in = yin && (unsigned)(x0 + c - 1) < (unsigned)a.w_;
+                const auto raw = __builtin_amdgcn_raw_buffer_load_b128(rsrc, in ? lane * 16 : 0x7FFFFFF0, in ? (pix0 + c) * a.ldx * 4 : 0, 0);
+                v[c] = make_float4(__uint_as_float(raw[0]), __uint_as_float(raw[1]), __uint_as_float(raw[2]), __uint_as_float(raw[3]));
+            }
+#pragma unroll
+            for (int c = 0; c < kPW + 2; ++c)
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    const int j = c - kx;            // output pixel x0 + j reads input column x0 + j + kx - 1 = x0 + c - 1
+                    if (j < 0 || j >= kPW) continue;
+                    const float4 q0 = w0[ky * 3 + kx], q1 = w1[ky * 3 + kx];
+                    float s0 = acc[2 * j], s1 = acc[2 * j + 1];
+                    s0 = fmaf(v[c].x, q0.x, s0); s0 = fmaf(v[c].y, q0.y, s0); s0 = fmaf(v[c].z, q0.z, s0); s0 = fmaf(v[c].w, q0.w, s0);
+                    s1 = fmaf(v[c].x, q1.x, s1); s1 = fmaf(v[c].y, q1.y, s1); s1 = fmaf(v[c].z, q1.z, s1); s1 = fmaf(v[c].w, q1.w, s1);
+                    acc[2 * j] = s0;
+                    acc[2 * j + 1] = s1;
+                }
+        }
+        // transposing butterfly: after the step with distance d the lane keeps half of its values, chosen by
+        // its bit d; 16 -> 8 -> 4 -> 2 -> 1 values, then two plain steps.  Lane l (l & 3 == 0) ends with the
+        // full sum of value id = bit5*8 + bit4*4 + bit3*2 + bit2.
+        static_assert(kPW == 8, "the butterfly below is written for 16 values");
+        float r8[8], r4[4], r2[2], r1;
+        {
+            const bool hi = (lane & 32) != 0;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const float send = hi ? acc[i] : acc[i + 8];
+                const float keep = hi ? acc[i + 8] : acc[i];
+                r8[i] = keep + __shfl_xor(send, 32, 64);
             }
         }
+        {
+            const bool hi = (lane & 16) != 0;
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
-            s0 += __shfl_xor(s0, off, 64);
-            s1 += __shfl_xor(s1, off, 64);
+            for (int i = 0; i < 4; ++i) {
+                const float send = hi ? r8[i] : r8[i + 4];
+                const float keep = hi ? r8[i + 4] : r8[i];
+                r4[i] = keep + __shfl_xor(send, 16, 64);
+            }
         }
-        if (lane < 2) {
-            const float delta = (lane == 0 ? s0 + b0 : s1 + b1);
-            const float c1 = a.coords1[(long)m * 2 + lane] + delta;
-            a.coords1[(long)m * 2 + lane] = c1;
-            const float fl = c1 - (float)(lane == 0 ? x : y);
-            a.hx_flow[(long)m * a.ldh + lane] = fl;
-            a.flow4[(long)m * 4 + lane] = fl;
+        {
+            const bool hi = (lane & 8) != 0;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const float send = hi ? r4[i] : r4[i + 2];
+                const float keep = hi ? r4[i + 2] : r4[i];
+                r2[i] = keep + __shfl_xor(send, 8, 64);
+            }
+        }
+        {
+            const bool hi = (lane & 4) != 0;
+            const float send = hi ? r2[0] : r2[1];
+            const float keep = hi ? r2[1] : r2[0];
+            r1 = keep + __shfl_xor(send, 4, 64);
+        }
+        r1 += __shfl_xor(r1, 2, 64);
+        r1 += __shfl_xor(r1, 1, 64);
+        const int id = ((lane >> 5) & 1) * 8 + ((lane >> 4) & 1) * 4 + ((lane >> 3) & 1) * 2 + ((lane >> 2) & 1);
+        const int j = id >> 1, o = id & 1;
+        const int x = x0 + j;
+        if ((lane & 3) == 0 && x < a.w_) {
+            const long m = (long)row * a.w_ + x;
+            const float c1 = a.coords1[m * 2 + o] + r1 + a.bias[o];
+            a.coords1[m * 2 + o] = c1;
+            const float fl = c1 - (float)(o == 0 ? x : y);
+            a.hx_flow[m * a.ldh + o] = fl;
+            a.flow4[m * 4 + o] = fl;
         }
     }
 }
@@ -67,9 +133,10 @@ int ofx_flow_head_launch(const float* x, int ldx, const float* w, int Kpad, cons
     a.x = x; a.w = w; a.bias = bias; a.coords1 = coords1; a.hx_flow = hx_flow; a.flow4 = flow4;
     a.ldx = ldx; a.ldh = ldh; a.Kpad = Kpad; a.h = h; a.w_ = w_;
     const long M = (long)B * h * w_;
-    OFX_REQUIRE(M < (1L << 31), OFX_EINVAL);
+    OFX_REQUIRE(M * ldx * 4 < (1L << 31) - 64, OFX_EINVAL);      // 32-bit byte offsets into x
     a.M = (int)M;
-    const int blocks = (int)std::min<long>((M + 3) / 4, 256L * 16);     // up to 16 workgroups per CU, grid-stride over pixels
+    const long strips = (M / w_) * ((w_ + kPW - 1) / kPW);
+    const int blocks = (int)std::min<long>((strips + 3) / 4, 256L * 16);   // one strip per wavefront, grid-stride beyond 16 workgroups per CU
     OfxProfScope prof("flow_head", s);
     hipLaunchKernelGGL(flow_head_kernel, dim3(blocks), dim3(256), 0, s, a);
     return ofx_launch_status();
