@@ -208,6 +208,8 @@ size_t ofx_raft_workspace_bytes(const ofx_raft* r, int B, int H, int W);
 #define OFX_RAFT_SHARED_IMG1  4   /* image1 is ONE image shared by the whole batch                 */
 #define OFX_RAFT_ALT_CORR     8   /* on-the-fly local correlation instead of the volume (alt_cuda_corr) */
 #define OFX_RAFT_BF16X3      16   /* opt-in: split-bf16 matrix-core arithmetic for every convolution / the volume */
+#define OFX_RAFT_SERIAL       32  /* keep every launch on the caller's stream (default: small batches run their
+                                     independent chains on internal side streams, joined before returning) */
 
 /* RAFT.forward(test_mode=True): image1/image2 u8 [B,H,W,3] on device -> flow_up f32[B,H,W,2]
  * (flow on image1's grid pointing into image2) and, if non-NULL, flow_low f32[B,H/8,W/8,2]. */

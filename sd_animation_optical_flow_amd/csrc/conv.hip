@@ -83,8 +83,13 @@ __device__ __forceinline__ float apply_act_rt(float v, int act) {
     }
 }
 
-template <int BM, int BN, int WM, int WN, int EPI, bool NORM, int BK, int PREC>
-__global__ __launch_bounds__(256, BK == 16 ? 3 : 1) void igemm_kernel(const ConvK p) {
+// KS = 2 ("paired pipelines", small grids only): the workgroup has a second set of four waves that runs the
+// same pipeline on its own LDS buffers over the odd K chunks while the first set takes the even ones; the
+// two accumulators are added through LDS before the epilogue.  A grid of one workgroup per CU is bound by the
+// latency of its two chunks in flight -- this doubles the loads in flight and the waves per SIMD without
+// touching the tile shape or the epilogue.
+template <int BM, int BN, int WM, int WN, int EPI, bool NORM, int BK, int PREC, int KS = 1>
+__global__ __launch_bounds__(256 * KS, (BK == 16 && KS == 1) ? 3 : 1) void igemm_kernel(const ConvK p) {
     constexpr int TM = WM / 32, TN = WN / 32;
     constexpr int WAVES_N = BN / WN;
     constexpr int LDK = BK + 4;               // LDS row stride in floats (144 B / 80 B): conflict-free b128 fragment reads
@@ -97,9 +102,13 @@ __global__ __launch_bounds__(256, BK == 16 ? 3 : 1) void igemm_kernel(const Conv
     constexpr int ROWB = BK * 2 + 16;                       // bytes per staged bf16 row
     constexpr int STAGE = PREC ? ((BM + BN) * ROWB * 2) / 4 : (BM + BN) * LDK;   // floats per stage
     static_assert((BM / WM) * (BN / WN) == 4, "4 waves per workgroup");
-    __shared__ __attribute__((aligned(16))) float smem[2 * STAGE];
+    static_assert(KS == 1 || KS == 2, "one or two pipelines");
+    static_assert(KS == 1 || 2 * STAGE * KS >= 256 * TM * TN * 16, "accumulator exchange must fit the staging buffers");
+    __shared__ __attribute__((aligned(16))) float smem_all[2 * STAGE * KS];
+    const int grp = KS == 1 ? 0 : (int)(threadIdx.x >> 8);      // pipeline this thread belongs to
+    float* const smem = smem_all + grp * (2 * STAGE);
 
-    const int tid = threadIdx.x;
+    const int tid = KS == 1 ? (int)threadIdx.x : (int)(threadIdx.x & 255);
     const int lane = tid & 63;
     const int wave = tid >> 6;
     const int wm = wave / WAVES_N;
@@ -159,7 +168,9 @@ __global__ __launch_bounds__(256, BK == 16 ? 3 : 1) void igemm_kernel(const Conv
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-    const int nk = p.Kpad / BK;
+    // chunks of this pipeline: grp, grp + KS, ...  (an index past the end addresses k >= K: the A operand
+    // reads as zero there, so the surplus iteration of the odd pipeline adds nothing)
+    const int nk = (p.Kpad / BK + KS - 1) / KS;
     const int frag_row = lane & 31;
     const int frag_k = (lane >> 5) * 4;
 
@@ -176,7 +187,7 @@ __global__ __launch_bounds__(256, BK == 16 ? 3 : 1) void igemm_kernel(const Conv
     auto offsets = [&](int chunk) __attribute__((always_inline)) {
         // byte offsets of chunk `chunk`: pure VALU, no memory access -> the scheduler interleaves it
         // with the MFMA block that follows it in the steady-state loop body
-        const int k0 = chunk * BK;
+        const int k0 = (chunk * KS + grp) * BK;
         const int k = k0 + kq * 4;
         const int tap = (int)__umulhi((unsigned)k, p.magic_cin);
         const int cch = k - tap * p.cin;
@@ -361,6 +372,27 @@ __global__ __launch_bounds__(256, BK == 16 ? 3 : 1) void igemm_kernel(const Conv
 #endif
     }
 
+    if constexpr (KS == 2) {
+        // add the two pipelines' accumulators: the odd one parks its tile in LDS and retires
+        __syncthreads();                                  // every wave is done reading the staging buffers
+        if (grp == 1) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) smem_all[((i * TN + j) * 16 + e) * 256 + tid] = acc[i][j][e];
+        }
+        __syncthreads();
+        if (grp == 1) return;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[i][j][e] += smem_all[((i * TN + j) * 16 + e) * 256 + tid];
+    }
+
     // ---- epilogue.  C/D layout of the 32x32 MFMA: col (n) = lane&31, row (m) = (e&3) + 8*(e>>2) + 4*(lane>>5).
     // Each 32x32 sub-tile runs in two phases -- every global read it needs (addend, residual, z, h) is
     // issued first, then the arithmetic and the stores.  The epilogue reads and writes the same buffers (h
@@ -475,18 +507,18 @@ __global__ __launch_bounds__(256, BK == 16 ? 3 : 1) void igemm_kernel(const Conv
     else epilogue(std::false_type{});
 }
 
-template <int BM, int BN, int WM, int WN, int BK, int PREC = 0>
+template <int BM, int BN, int WM, int WN, int BK, int PREC = 0, int KS = 1>
 int launch_tile(const ConvK& k, int epi, bool norm, int nz, hipStream_t s) {
     dim3 grid((unsigned)(k.mtiles * k.ntiles), (unsigned)nz, 1);
-    dim3 block(256, 1, 1);
+    dim3 block(256 * KS, 1, 1);
     switch (epi) {
         case OFX_EPI_PLAIN:
-            if (norm) hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, OFX_EPI_PLAIN, true, BK, PREC>), grid, block, 0, s, k);
-            else hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, OFX_EPI_PLAIN, false, BK, PREC>), grid, block, 0, s, k);
+            if (norm) hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, OFX_EPI_PLAIN, true, BK, PREC, KS>), grid, block, 0, s, k);
+            else hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, OFX_EPI_PLAIN, false, BK, PREC, KS>), grid, block, 0, s, k);
             break;
-        case OFX_EPI_GRU_ZR: hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, OFX_EPI_GRU_ZR, false, BK, PREC>), grid, block, 0, s, k); break;
-        case OFX_EPI_GRU_Q: hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, OFX_EPI_GRU_Q, false, BK, PREC>), grid, block, 0, s, k); break;
-        case OFX_EPI_FLOW: hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, OFX_EPI_FLOW, false, BK, PREC>), grid, block, 0, s, k); break;
+        case OFX_EPI_GRU_ZR: hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, OFX_EPI_GRU_ZR, false, BK, PREC, KS>), grid, block, 0, s, k); break;
+        case OFX_EPI_GRU_Q: hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, OFX_EPI_GRU_Q, false, BK, PREC, KS>), grid, block, 0, s, k); break;
+        case OFX_EPI_FLOW: hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, OFX_EPI_FLOW, false, BK, PREC, KS>), grid, block, 0, s, k); break;
         default: return OFX_EINVAL;
     }
     return ofx_launch_status();
@@ -623,11 +655,14 @@ extern "C" int ofx_conv2d_alpha(const ofx_conv_desc* d, float alpha, void* strea
     prof.flops(2.0 * (double)M * d->Cout * k.K * nz);
     // BK = 16 keeps LDS at 41 KB and registers under 168 for the 128x128 tile -> 3 workgroups per CU; the
     // extra resident wave per SIMD hides the commit/barrier/issue phases better than a longer chunk does
-    // (measured +4..10 % on every shape).  tile = BK*1e6 + BM*1e3 + BN overrides.
-    const int bk = d->tile >= 1000000 ? d->tile / 1000000 : (bn == 32 ? 32 : 16);
+    // (measured +4..10 % on every shape).  The 64x64 tile is only chosen for grids that under-fill the
+    // machine (one workgroup per CU or fewer): there each chunk's load latency is exposed and the longer
+    // chunk wins (+8..20 % at one 512x768 pair).  tile = BK*1e6 + BM*1e3 + BN overrides.
+    const int tile_bk = (d->tile % 1000000000) / 1000000;
+    const int bk = tile_bk ? tile_bk : ((bn == 32 || bm == 64) ? 32 : 16);
     if (d->precision == OFX_PREC_BF16X3) {
         // split-bf16 matrix-core path (opt-in): the three tiles below; anything else falls through to fp32
-        if (bm == 128 && bn == 128 && d->tile >= 32000000) return launch_tile<128, 128, 64, 64, 32, 1>(k, d->epi, norm, nz, s);
+        if (bm == 128 && bn == 128 && tile_bk == 32) return launch_tile<128, 128, 64, 64, 32, 1>(k, d->epi, norm, nz, s);
         if (bm == 128 && bn == 128) return launch_tile<128, 128, 64, 64, 16, 1>(k, d->epi, norm, nz, s);
         if (bm == 128 && bn == 64) return launch_tile<128, 64, 64, 32, 16, 1>(k, d->epi, norm, nz, s);
         if (bm == 64 && bn == 64) return launch_tile<64, 64, 32, 32, 16, 1>(k, d->epi, norm, nz, s);
@@ -638,6 +673,10 @@ extern "C" int ofx_conv2d_alpha(const ofx_conv_desc* d, float alpha, void* strea
     if (bm == 128 && bn == 64) return launch_tile<128, 64, 64, 32, 32>(k, d->epi, norm, nz, s);
     if (bm == 128 && bn == 32) return launch_tile<128, 32, 32, 32, 32>(k, d->epi, norm, nz, s);
     if (bm == 64 && bn == 64 && bk == 16) return launch_tile<64, 64, 32, 32, 16>(k, d->epi, norm, nz, s);
+    // a grid of at most ~2 workgroups per CU is latency-bound: pair the pipelines (tile + 2e9 forces it, an explicit tile without that forbids it)
+    const long blocks = (long)k.mtiles * k.ntiles * nz;
+    const bool pair = d->tile >= 2000000000 || (d->tile < 1000000 && blocks <= 640 && k.Kpad >= 8 * 32);
+    if (bm == 64 && bn == 64 && pair) return launch_tile<64, 64, 32, 32, 32, 0, 2>(k, d->epi, norm, nz, s);
     if (bm == 64 && bn == 64) return launch_tile<64, 64, 32, 32, 32>(k, d->epi, norm, nz, s);
     return OFX_EINVAL;
 }

@@ -71,6 +71,13 @@ static inline int enc_chunk(int H, int W) {
     return (int)std::max<long>(1, std::min<long>(ENC_CHUNK, fit));
 }
 
+// A single pair at 512x768 gives the convolution kernels 100-400 workgroups per launch on a 256-CU part: the
+// machine is under-filled and each launch is latency-bound.  Below this many 1/8-resolution pixels the
+// executor therefore runs the independent chains of a forward side by side on separate HIP streams (the
+// three encoders; the flow branch of the motion encoder next to the correlation branch).  Large batches fill
+// the machine with every launch and stay on one stream.
+static inline bool overlap_pays(long M) { return M <= 32768; }
+
 struct Carver {
     char* base;
     size_t off = 0, cap;
@@ -89,6 +96,10 @@ struct ofx_raft {
     std::map<std::string, ConvW> convs;
     std::vector<void*> allocs;
     std::map<std::string, std::pair<void*, size_t>> bufs;
+    // side streams for the small-batch schedule (see overlap_pays): independent chains of a forward run
+    // concurrently and are joined back into the caller's stream with events
+    hipStream_t aux[2] = {nullptr, nullptr};
+    hipEvent_t ev_fork = nullptr, ev_join[2] = {nullptr, nullptr};
 };
 
 namespace {
@@ -288,6 +299,25 @@ struct Launcher {
     }
 };
 
+struct Streams {
+    ofx_raft* r;
+    hipStream_t main;
+    bool on;
+    hipStream_t get(int i) const { return on ? r->aux[i] : main; }
+    int fork(int i) const {   // side stream i waits for everything enqueued on the caller's stream so far
+        if (!on) return 0;
+        OFX_HIP_CHECK(hipEventRecord(r->ev_fork, main));
+        OFX_HIP_CHECK(hipStreamWaitEvent(r->aux[i], r->ev_fork, 0));
+        return 0;
+    }
+    int join(int i) const {   // the caller's stream waits for side stream i
+        if (!on) return 0;
+        OFX_HIP_CHECK(hipEventRecord(r->ev_join[i], r->aux[i]));
+        OFX_HIP_CHECK(hipStreamWaitEvent(main, r->ev_join[i], 0));
+        return 0;
+    }
+};
+
 struct EncBufs {
     float *x0, *X, *Y, *R1, *R2, *R3;
     float* stats;     // 6 x [chunk][128] floats (mean/rstd for up to 3 norms)
@@ -375,7 +405,7 @@ static int run_encoder(ofx_raft* r, const std::string& enc, bool bn, const uint8
 
 // workspace layout shared by the size query and the forward
 struct RaftWs {
-    EncBufs eb;
+    EncBufs eb[3];    // [1], [2] only exist (else alias [0]) when the encoders may run concurrently
     float *fmap1, *fmap2, *f2l[LEVELS];
     float* ctx;       // indexed-pairs mode: per-image context features [n][N][256] (tanh | relu halves)
     int* idx_dev;     // indexed-pairs mode: image1 index per pair
@@ -394,14 +424,21 @@ static RaftWs carve(void* base, size_t cap, int B, int H, int W, int flags, int 
     const int most = n_images > 0 ? n_images : 2 * B;
     const int nch = std::min(enc_chunk(H, W), most);
     const long half = (long)(H / 2) * (W / 2) * 64;
-    w.eb.x0 = c.take((size_t)nch * H * W * 4);
-    w.eb.X = c.take((size_t)nch * half);
-    w.eb.Y = c.take((size_t)nch * half);
-    w.eb.R1 = c.take((size_t)nch * half);
-    w.eb.R2 = c.take((size_t)nch * half);
-    w.eb.R3 = c.take((size_t)nch * (H / 4) * (W / 4) * 96);
-    w.eb.stats = c.take((size_t)6 * ENC_CHUNK * 128);
-    w.eb.scratch = c.take((size_t)ENC_CHUNK * 64 * 128 * 2 * 2);   // doubles: chunk x slices x C x {sum, sumsq}
+    for (int e = 0; e < 3; ++e) {
+        if (e > 0 && !overlap_pays(M)) {
+            w.eb[e] = w.eb[0];
+            continue;
+        }
+        EncBufs& eb = w.eb[e];
+        eb.x0 = c.take((size_t)nch * H * W * 4);
+        eb.X = c.take((size_t)nch * half);
+        eb.Y = c.take((size_t)nch * half);
+        eb.R1 = c.take((size_t)nch * half);
+        eb.R2 = c.take((size_t)nch * half);
+        eb.R3 = c.take((size_t)nch * (H / 4) * (W / 4) * 96);
+        eb.stats = c.take((size_t)6 * ENC_CHUNK * 128);
+        eb.scratch = c.take((size_t)ENC_CHUNK * 64 * 128 * 2 * 2);   // doubles: chunk x slices x C x {sum, sumsq}
+    }
     long n1 = (flags & OFX_RAFT_SHARED_IMG1) ? 1 : B, n2 = (flags & OFX_RAFT_SHARED_IMG2) ? 1 : B;
     if (n_images > 0) {
         n1 = n_images;
@@ -435,7 +472,7 @@ static RaftWs carve(void* base, size_t cap, int B, int H, int W, int flags, int 
 // everything after the feature / context encoders and the correlation volume: state init, the loop-invariant
 // GRU terms, `iters` refinement iterations, mask head, convex upsample
 static int run_recurrence(ofx_raft* r, const RaftWs& ws, int B, int h, int w, int iters, bool alt, bool shared,
-                          float* flow_up, float* flow_low, hipStream_t s, int precision = OFX_PREC_FP32) {
+                          float* flow_up, float* flow_low, hipStream_t s, int precision, bool overlap) {
     const long N = (long)h * w;
     const bool sh1 = shared, sh2 = shared;
     int st = 0;
@@ -454,10 +491,18 @@ static int run_recurrence(ofx_raft* r, const RaftWs& ws, int B, int h, int w, in
 
     Launcher L{s};
     L.precision = precision;
+    const Streams S{r, s, overlap};
+    Launcher LF{S.get(0)};   // flow branch of the motion encoder: independent of the correlation branch
+    LF.precision = precision;
     auto C = [&](const char* k) -> const ConvW& { return r->convs[k]; };
     const float* pyr_c[LEVELS] = {ws.pyr[0], ws.pyr[1], ws.pyr[2], ws.pyr[3]};
     const int rd2 = (2 * RADIUS + 1) * (2 * RADIUS + 1);
     for (int it = 0; it < iters && !L.st; ++it) {
+        // flow features (update.py:93-94) on the side stream, from the flow the previous iteration left
+        if ((L.st = S.fork(0))) break;
+        LF.conv(C("convf1"), ws.flow4, 4, 4, nullptr, 0, 0, ws.f1, 128, B, h, w, 1, OFX_ACT_RELU);
+        LF.conv(C("convf2"), ws.f1, 128, 128, nullptr, 0, 0, ws.corflo + 192, 256, B, h, w, 1, OFX_ACT_RELU);
+        if ((L.st = LF.st)) break;
         // correlation features at the current estimate
         if (!alt) {
             L.st = ofx_corr_lookup(pyr_c, ws.coords1, ws.corr, CORR_CH, B, h, w, LEVELS, RADIUS, s);
@@ -472,8 +517,7 @@ static int run_recurrence(ofx_raft* r, const RaftWs& ws, int B, int h, int w, in
         // motion encoder (update.py:88-97)
         L.conv(C("convc1"), ws.corr, CORR_CH, CORR_CH, nullptr, 0, 0, ws.c1, 256, B, h, w, 1, OFX_ACT_RELU);
         L.conv(C("convc2"), ws.c1, 256, 256, nullptr, 0, 0, ws.corflo, 256, B, h, w, 1, OFX_ACT_RELU);
-        L.conv(C("convf1"), ws.flow4, 4, 4, nullptr, 0, 0, ws.f1, 128, B, h, w, 1, OFX_ACT_RELU);
-        L.conv(C("convf2"), ws.f1, 128, 128, nullptr, 0, 0, ws.corflo + 192, 256, B, h, w, 1, OFX_ACT_RELU);
+        if (!L.st) L.st = S.join(0);
         L.conv(C("conv"), ws.corflo, 256, 256, nullptr, 0, 0, ws.hx + MOT_OFF, HX_LD, B, h, w, 1, OFX_ACT_RELU);
         // SepConvGRU (update.py:44-60): horizontal then vertical pass
         for (int pass = 1; pass <= 2; ++pass) {
@@ -541,6 +585,11 @@ int ofx_raft_create(const ofx_tensor* tensors, int n, ofx_raft** out) {
     if (!st) st = add_conv(r, sd, std::string(ub) + "flow_head.conv2", "fh2", 0, "", 1.f);
     if (!st) st = add_conv(r, sd, std::string(ub) + "mask.0", "mask0", 0, "", 1.f);
     if (!st) st = add_conv(r, sd, std::string(ub) + "mask.2", "mask2", 0, "", 0.25f);
+    for (int i = 0; i < 2 && !st; ++i) {
+        if (hipStreamCreateWithFlags(&r->aux[i], hipStreamNonBlocking) != hipSuccess) st = OFX_ENODEV;
+        if (!st && hipEventCreateWithFlags(&r->ev_join[i], hipEventDisableTiming) != hipSuccess) st = OFX_ENODEV;
+    }
+    if (!st && hipEventCreateWithFlags(&r->ev_fork, hipEventDisableTiming) != hipSuccess) st = OFX_ENODEV;
     if (st) {
         ofx_raft_destroy(r);
         return st;
@@ -552,6 +601,11 @@ int ofx_raft_create(const ofx_tensor* tensors, int n, ofx_raft** out) {
 int ofx_raft_destroy(ofx_raft* r) {
     if (!r) return 0;
     for (void* p : r->allocs) (void)hipFree(p);
+    for (int i = 0; i < 2; ++i) {
+        if (r->aux[i]) (void)hipStreamDestroy(r->aux[i]);
+        if (r->ev_join[i]) (void)hipEventDestroy(r->ev_join[i]);
+    }
+    if (r->ev_fork) (void)hipEventDestroy(r->ev_fork);
     delete r;
     return 0;
 }
@@ -582,32 +636,41 @@ int ofx_raft_forward(ofx_raft* r, const uint8_t* image1, const uint8_t* image2, 
     const bool alt = flags & OFX_RAFT_ALT_CORR;
     const long img_bytes = (long)H * W * 3;
 
-    // ---- feature encoders (instance norm => per-image statistics, so chunking is exact)
+    // ---- encoders (instance norm => per-image statistics, so chunking is exact).  Three independent chains:
+    // fnet(image1) on the caller's stream, fnet(image2) and cnet(image1) on the side streams when the batch is
+    // too small to fill the machine by itself.
     int st = 0;
     const int n1 = sh1 ? 1 : B, n2 = sh2 ? 1 : B;
-    for (int i0 = 0; i0 < n1 && !st; i0 += enc_chunk(H, W)) {
-        const int n = std::min(enc_chunk(H, W), n1 - i0);
-        st = run_encoder(r, "fnet", false, image1 + i0 * img_bytes, n, H, W, bgr, ws.eb, ws.fmap1 + (long)i0 * N * FD, FD,
+    const bool overlap = overlap_pays(M) && !(flags & OFX_RAFT_SERIAL);
+    const Streams S{r, s, overlap};
+    const int ech = enc_chunk(H, W);
+    if ((st = S.fork(0))) return st;
+    if ((st = S.fork(1))) return st;
+    for (int i0 = 0; i0 < n1 && !st; i0 += ech) {
+        const int n = std::min(ech, n1 - i0);
+        st = run_encoder(r, "fnet", false, image1 + i0 * img_bytes, n, H, W, bgr, ws.eb[0], ws.fmap1 + (long)i0 * N * FD, FD,
                          false, 0, s, prec);
     }
-    for (int i0 = 0; i0 < n2 && !st; i0 += enc_chunk(H, W)) {
-        const int n = std::min(enc_chunk(H, W), n2 - i0);
-        st = run_encoder(r, "fnet", false, image2 + i0 * img_bytes, n, H, W, bgr, ws.eb, ws.fmap2 + (long)i0 * N * FD, FD,
-                         false, 0, s, prec);
+    for (int i0 = 0; i0 < n2 && !st; i0 += ech) {
+        const int n = std::min(ech, n2 - i0);
+        st = run_encoder(r, "fnet", false, image2 + i0 * img_bytes, n, H, W, bgr, ws.eb[1], ws.fmap2 + (long)i0 * N * FD, FD,
+                         false, 0, S.get(0), prec);
     }
-    // ---- context encoder on image1 -> hx[:, 0:128] = tanh (net), hx[:, 256:384] = relu (inp)
+    // context encoder on image1 -> hx[:, 0:128] = tanh (net), hx[:, 256:384] = relu (inp)
     if (sh1) {
-        if (!st) st = run_encoder(r, "cnet", true, image1, 1, H, W, bgr, ws.eb, ws.hx, HX_LD, true, INP_OFF, s, prec);
+        if (!st) st = run_encoder(r, "cnet", true, image1, 1, H, W, bgr, ws.eb[2], ws.hx, HX_LD, true, INP_OFF, S.get(1), prec);
         for (int k = 1; k < B && !st; ++k)   // one shared image1: replicate its context rows
             OFX_HIP_CHECK(hipMemcpyAsync(ws.hx + (long)k * N * HX_LD, ws.hx, (size_t)N * HX_LD * sizeof(float),
-                                         hipMemcpyDeviceToDevice, s));
+                                         hipMemcpyDeviceToDevice, S.get(1)));
     } else {
-        for (int i0 = 0; i0 < B && !st; i0 += enc_chunk(H, W)) {
-            const int n = std::min(enc_chunk(H, W), B - i0);
-            st = run_encoder(r, "cnet", true, image1 + i0 * img_bytes, n, H, W, bgr, ws.eb, ws.hx + (long)i0 * N * HX_LD,
-                             HX_LD, true, INP_OFF, s, prec);
+        for (int i0 = 0; i0 < B && !st; i0 += ech) {
+            const int n = std::min(ech, B - i0);
+            st = run_encoder(r, "cnet", true, image1 + i0 * img_bytes, n, H, W, bgr, ws.eb[2], ws.hx + (long)i0 * N * HX_LD,
+                             HX_LD, true, INP_OFF, S.get(1), prec);
         }
     }
+    if (!st) st = S.join(0);
+    if (!st) st = S.join(1);
     if (st) return st;
 
     // ---- correlation
@@ -631,7 +694,7 @@ int ofx_raft_forward(ofx_raft* r, const uint8_t* image1, const uint8_t* image2, 
         if (st) return st;
     }
 
-    st = run_recurrence(r, ws, B, h, w, iters, alt, sh1 || sh2, flow_up, flow_low, s, prec);
+    st = run_recurrence(r, ws, B, h, w, iters, alt, sh1 || sh2, flow_up, flow_low, s, prec, overlap);
     if (st) return st;
 
     r->bufs.clear();
@@ -677,14 +740,18 @@ int ofx_raft_forward_pairs(ofx_raft* r, const uint8_t* images, int n_images, con
     int st = 0;
     // every image is encoded ONCE (feature + context), however many pairs it takes part in: a 15-frame
     // KeyframeConv window has 210 ordered pairs but only 15 images (ofgen_keyframe_inpaint.py:627-668)
+    const bool overlap = overlap_pays((long)B * N) && !(flags & OFX_RAFT_SERIAL);
+    const Streams S{r, s, overlap};
+    if ((st = S.fork(1))) return st;
     for (int i0 = 0; i0 < n_images && !st; i0 += enc_chunk(H, W)) {
         const int n = std::min(enc_chunk(H, W), n_images - i0);
-        st = run_encoder(r, "fnet", false, images + i0 * img_bytes, n, H, W, bgr, ws.eb, ws.fmap1 + (long)i0 * N * FD, FD, false,
-                         0, s, prec);
+        st = run_encoder(r, "fnet", false, images + i0 * img_bytes, n, H, W, bgr, ws.eb[0], ws.fmap1 + (long)i0 * N * FD, FD,
+                         false, 0, s, prec);
         if (!st)
-            st = run_encoder(r, "cnet", true, images + i0 * img_bytes, n, H, W, bgr, ws.eb, ws.ctx + (long)i0 * N * (HD + CD),
-                             HD + CD, true, HD, s, prec);
+            st = run_encoder(r, "cnet", true, images + i0 * img_bytes, n, H, W, bgr, ws.eb[2], ws.ctx + (long)i0 * N * (HD + CD),
+                             HD + CD, true, HD, S.get(1), prec);
     }
+    if (!st) st = S.join(1);
     if (st) return st;
     OFX_HIP_CHECK(hipMemcpyAsync(ws.idx_dev, idx1, sizeof(int) * B, hipMemcpyHostToDevice, s));
     st = ofx_ctx_gather(ws.ctx, ws.idx_dev, ws.hx, HX_LD, INP_OFF, HD, B, N, s);
@@ -702,7 +769,7 @@ int ofx_raft_forward_pairs(ofx_raft* r, const uint8_t* images, int n_images, con
     }
     if (!st) st = ofx_corr_pool_launch(ws.pyr[0], ws.pyr[1], ws.pyr[2], ws.pyr[3], B, h, w, LEVELS, s);
     if (st) return st;
-    st = run_recurrence(r, ws, B, h, w, iters, false, false, flow_up, flow_low, s, prec);
+    st = run_recurrence(r, ws, B, h, w, iters, false, false, flow_up, flow_low, s, prec, overlap);
     if (st) return st;
     r->bufs.clear();
     return 0;

@@ -154,3 +154,20 @@ def test_batch_consistency_512x768(engine):
     single = engine.forward(frames[1:2].cuda(), key.cuda(), iters=3)
     assert torch.isfinite(up).all()
     assert (up[1:2] - single).abs().max().item() < 1e-4
+
+
+def test_small_batch_stream_overlap_is_bit_identical_to_serial(engine):
+    """B <= 5 at 512x768 runs the three encoders and the two motion-encoder branches on side streams; the
+    kernels and their arithmetic are the same, so the flow must be bit-identical to the one-stream schedule,
+    also when calls alternate back to back (the side streams are joined before the call returns)."""
+    for (H, W, B, seed) in ((384, 512, 1, 21), (768, 512, 2, 22)):
+        key, frames = _frames(seed, B, H, W)
+        a, k = frames.cuda(), key.cuda()
+        ser = engine.forward(a, k, iters=12, serial=True)
+        for _ in range(3):
+            ovl = engine.forward(a, k, iters=12)
+            assert torch.equal(ovl, ser)
+        both = engine.forward(a, a.flip(0).contiguous(), iters=5)            # per-pair image2: third encoder chain
+        assert torch.equal(both, engine.forward(a, a.flip(0).contiguous(), iters=5, serial=True))
+    out = engine.forward_pairs(torch.cat([key[None], frames]).cuda(), [1, 0], [0, 2], iters=6)
+    assert torch.isfinite(out).all()
