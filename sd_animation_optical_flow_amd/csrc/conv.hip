@@ -634,13 +634,14 @@ extern "C" int ofx_conv2d_alpha(const ofx_conv_desc* d, float alpha, void* strea
         auto waste = [&](int t) { return (double)(((d->Cout + t - 1) / t) * t) / d->Cout; };
         if (d->Cout <= 32) bn = 32;
         else if (waste(128) <= 1.13) bn = 128;
+        else if (waste(192) <= 1.05 && d->precision == OFX_PREC_FP32 && !d->nmean && d->epi != OFX_EPI_FLOW) bn = 192;   // 192-channel layers: one 128x192 tile instead of 128x64 x 3
         else if (waste(64) <= 1.13) bn = 64;
         else if (waste(32) < waste(64) - 0.1) bn = 32;
         else bn = 64;
         bm = 128;
         const long blocks128 = ((M + 127) / 128) * ((d->Cout + bn - 1) / bn) * nz;
         if (bn >= 64 && blocks128 < 1024) bm = 64;   // under ~4 waves of 256 CUs: smaller tiles fill the chip
-        if (bm == 64 && bn == 128) bn = 64;
+        if (bm == 64 && bn >= 128) bn = 64;
     }
     k.mtiles = (int)((M + bm - 1) / bm);
     k.ntiles = (d->Cout + bn - 1) / bn;
@@ -667,6 +668,7 @@ extern "C" int ofx_conv2d_alpha(const ofx_conv_desc* d, float alpha, void* strea
         if (bm == 128 && bn == 64) return launch_tile<128, 64, 64, 32, 16, 1>(k, d->epi, norm, nz, s);
         if (bm == 64 && bn == 64) return launch_tile<64, 64, 32, 32, 16, 1>(k, d->epi, norm, nz, s);
     }
+    if (bm == 128 && bn == 192) return launch_tile<128, 192, 64, 96, 16>(k, d->epi, norm, nz, s);
     if (bm == 128 && bn == 128 && bk == 16) return launch_tile<128, 128, 64, 64, 16>(k, d->epi, norm, nz, s);
     if (bm == 128 && bn == 64 && bk == 16) return launch_tile<128, 64, 64, 32, 16>(k, d->epi, norm, nz, s);
     if (bm == 128 && bn == 128) return launch_tile<128, 128, 64, 64, 32>(k, d->epi, norm, nz, s);
