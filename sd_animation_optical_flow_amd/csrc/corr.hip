@@ -36,6 +36,34 @@ __global__ __launch_bounds__(256) void pyramid_pool_kernel(const PoolArgs a) {
     const float* src = a.l0 + p * (long)a.h0 * a.w0;
     float* d1 = a.l1 + p * (long)a.h1 * a.w1;
     const int n1 = a.h1 * a.w1;
+    if ((a.w0 & 3) == 0) {
+        // rows are 16-byte aligned: one thread pools two horizontally adjacent outputs from two float4 loads,
+        // four such pairs per trip so that 8 x 16 B are in flight per lane (same additions, same order)
+        const int wp = a.w1 >> 1;                  // output pairs per row
+        const int npair = a.h1 * wp;
+        for (int i0 = 0; i0 < npair; i0 += 4 * 256) {
+            float4 t[4], u[4];
+            int o[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int i = min(i0 + q * 256 + (int)threadIdx.x, npair - 1);
+                const int y = i / wp, x2 = i - y * wp;
+                o[q] = y * a.w1 + 2 * x2;
+                const float* r = src + (long)(2 * y) * a.w0 + 4 * x2;
+                t[q] = *reinterpret_cast<const float4*>(r);
+                u[q] = *reinterpret_cast<const float4*>(r + a.w0);
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                if (i0 + q * 256 + (int)threadIdx.x >= npair) continue;
+                float2 v;
+                v.x = (((t[q].x + t[q].y) + u[q].x) + u[q].y) * 0.25f;   // avg_pool2d: window sum, then /4
+                v.y = (((t[q].z + t[q].w) + u[q].z) + u[q].w) * 0.25f;
+                *reinterpret_cast<float2*>(d1 + o[q]) = v;
+                *reinterpret_cast<float2*>(s1 + o[q]) = v;
+            }
+        }
+    } else
     for (int i = threadIdx.x; i < n1; i += 256) {
         const int y = i / a.w1, x = i - y * a.w1;
         float2 t, u;
@@ -153,7 +181,11 @@ __global__ __launch_bounds__(256) void corr_lookup_kernel(const LookupArgs a) {
             s[t] = v;
         }
     }
-    __syncthreads();
+    // each wavefront owns its LDS window (win[wave]): LDS operations of one wave complete in order, so a
+    // wave-level fence is enough and the four pixels of a workgroup never wait for each other
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     if (!live) return;
     float* o = a.out + m * (long)a.ldo;
     const int rd2 = rd * rd;

@@ -1,0 +1,57 @@
+#!/usr/bin/env python3
+"""HBM bytes per launch from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) of the same bench command.
+
+    python tools/pmc_traffic.py <fetch pmc_results.db> <write pmc_results.db> > profiles/rNN_pmc_traffic_b64.json
+
+Units and corrections as /opt/skills/guides/MI355X_MICROARCH.md prescribes for gfx950: both counters are in KiB;
+FETCH_SIZE under-reports by 2x on this part (64-byte requests are counted as 32 bytes), WRITE_SIZE needs no
+correction.  bytes/launch = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 / dispatches.  Kernels are grouped into the
+families bench.py reports.
+"""
+import json
+import sqlite3
+import sys
+
+FAMILIES = [
+    ("igemm_conv_all", lambda n, gy: "igemm_kernel" in n and gy <= 1),
+    ("corr_volume_gemm", lambda n, gy: "igemm_kernel" in n and gy > 1),
+    ("corr_lookup", lambda n, gy: "corr_lookup_kernel" in n),
+    ("pyramid_pool", lambda n, gy: "pyramid_pool_kernel" in n),
+    ("upsample", lambda n, gy: "upsample_kernel" in n),
+    ("flow_head", lambda n, gy: "flow_head_kernel" in n),
+    ("warp", lambda n, gy: "warp_u8c3_x4_kernel" in n or "warp_kernel" in n),
+    ("mask", lambda n, gy: "mask_bits_kernel" in n),
+]
+
+
+def collect(db, counter):
+    c = sqlite3.connect(db)
+    out = {}
+    q = "select kernel_name, grid_size_y, count(*), sum(value) from counters_collection where counter_name = ? group by kernel_name, grid_size_y"
+    for name, gy, n, v in c.execute(q, (counter,)):
+        for fam, match in FAMILIES:
+            if match(name, gy or 1):
+                a = out.setdefault(fam, [0, 0.0])
+                a[0] += n
+                a[1] += v
+                break
+    return out
+
+
+def main():
+    fetch = collect(sys.argv[1], "FETCH_SIZE")
+    write = collect(sys.argv[2], "WRITE_SIZE")
+    res = {}
+    for fam in fetch:
+        n, f = fetch[fam]
+        nw, w = write.get(fam, (n, 0.0))
+        n = max(n, 1)
+        fb, wb = f * 1024.0 / n, w * 1024.0 / max(nw, 1)
+        res[fam] = {"launches": n, "fetch_bytes_per_launch_raw": fb, "write_bytes_per_launch": wb,
+                    "hbm_bytes_per_launch_corrected": 2.0 * fb + wb}
+    json.dump(res, sys.stdout, indent=1)
+    print()
+
+
+if __name__ == "__main__":
+    main()
