@@ -326,13 +326,16 @@ def main():
         # HBM bytes per launch from the committed PMC passes of this same command (rocprofv3 --pmc FETCH_SIZE /
         # WRITE_SIZE in separate runs; FETCH_SIZE doubled per the gfx950 correction, calibrated on the pooling
         # kernel: corrected 12.83 GB = its exact algorithmic 12.83 GB).  PMC cannot be collected inside this run.
-        tp = os.path.join(ROOT, "profiles", "r01b_pmc_traffic_b64.json")
-        if B == 64 and os.path.exists(tp):
+        import glob
+        tps = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic_b64.json")))   # newest round last
+        if B == 64 and tps:
+            tp = tps[-1]
             tr = json.load(open(tp))
             if "roofline" in out and "igemm_conv_all" in tr:
                 out["roofline"]["traffic"] = tr["igemm_conv_all"]["hbm_bytes_per_launch_corrected"]
-                out["roofline"]["traffic_source"] = "profiles/r01b_pmc_traffic_b64.json (avg over all igemm launches)"
-            for label, tkey in (("corr_lookup", "corr_lookup"), ("corr_pyramid_pool", "pyramid_pool"), ("upsample_flow", "upsample"),
+                out["roofline"]["traffic_source"] = f"profiles/{os.path.basename(tp)} (avg over all convolution launches)"
+            for label, tkey in (("corr_volume_gemm", "corr_volume_gemm"), ("corr_lookup", "corr_lookup"),
+                               ("corr_pyramid_pool", "pyramid_pool"), ("upsample_flow", "upsample"),
                                ("warp", "warp"), ("mask", "mask")):
                 if label in ks and tkey in tr:
                     ks[label]["traffic"] = tr[tkey]["hbm_bytes_per_launch_corrected"]

@@ -63,6 +63,7 @@ struct ConvK {
     int Hin, Win, Hout, Wout, Cout, KW, stride, padH, padW;
     int K, Kpad, M, act;
     int mtiles, ntiles;
+    int group_m;                    // > 1: tiles are ordered M-fastest inside groups of group_m M-tiles (wide-N GEMMs)
     float alpha;
     unsigned magic_cin, magic_kw;   // ceil(2^32/d) for d = cin, KW (0 when d == 1): k/d = umulhi(k, magic)
     unsigned kw1_mask;              // all ones when KW == 1 (then tap / KW = tap), else 0
@@ -122,8 +123,22 @@ __global__ __launch_bounds__(256 * KS, (BK == 16 && KS == 1) ? 3 : 1) void igemm
     const int q8 = nblk >> 3, r8 = nblk & 7;
     const int xcd = bid & 7, idx = bid >> 3;
     const int L = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
-    const int nt = L % p.ntiles;
-    const int mt = L / p.ntiles;
+    // Few N-tiles (every convolution): N fastest, the N-tiles of one A tile run back to back.  Many N-tiles (the
+    // correlation volume, 48 x 48 tiles per pair): a sweep over all of N streams the whole B operand (6.3 MB)
+    // through the 4 MB L2 once per M-tile, so tiles are walked M-fastest inside groups of group_m M-tiles --
+    // the workgroups in flight then share a few A tiles and a few B tiles that all stay resident.
+    int nt, mt;
+    if (p.group_m <= 1) {
+        nt = L % p.ntiles;
+        mt = L / p.ntiles;
+    } else {
+        const int per = p.group_m * p.ntiles;
+        const int g = L / per;
+        const int rem = L - g * per;
+        const int gm = min(p.group_m, p.mtiles - g * p.group_m);   // the last group may be short
+        nt = rem / gm;
+        mt = g * p.group_m + (rem - nt * gm);
+    }
     const int m0 = mt * BM;
     const int n0 = nt * BN;
     const int z = blockIdx.y;
@@ -645,6 +660,7 @@ extern "C" int ofx_conv2d_alpha(const ofx_conv_desc* d, float alpha, void* strea
     }
     k.mtiles = (int)((M + bm - 1) / bm);
     k.ntiles = (d->Cout + bn - 1) / bn;
+    k.group_m = k.ntiles >= 8 ? 8 : 1;
     hipStream_t s = (hipStream_t)stream;
     const bool norm = d->nmean != nullptr;
     const char* pname = nz > 1 ? "igemm_corr_volume"

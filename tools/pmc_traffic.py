@@ -4,8 +4,10 @@
     python tools/pmc_traffic.py <fetch pmc_results.db> <write pmc_results.db> > profiles/rNN_pmc_traffic_b64.json
 
 Units and corrections as /opt/skills/guides/MI355X_MICROARCH.md prescribes for gfx950: both counters are in KiB;
-FETCH_SIZE under-reports by 2x on this part (64-byte requests are counted as 32 bytes), WRITE_SIZE needs no
-correction.  bytes/launch = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 / dispatches.  Kernels are grouped into the
+FETCH_SIZE reports half of the bytes of wide coalesced reads on this part (128-byte requests tallied at 64 B) and
+is doubled; WRITE_SIZE is taken as is.  Calibration in our own access pattern: the pooling kernel (reads the
+whole level-0 volume once, writes levels 1-3 once) comes out at its exact algorithmic byte count.
+bytes/launch = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 / dispatches.  Kernels are grouped into the
 families bench.py reports.
 """
 import json
