@@ -147,7 +147,9 @@ typedef struct ofx_conv_desc {
     long a_zs, w_zs, o_zs; int nz;               /* batched-GEMM mode (nz>1): per-z strides in elements */
     int B, Hin, Win, Hout, Wout, Cout, KH, KW, stride, padH, padW;
     int act, epi;
-    int tile;                                    /* 0 = auto; else BK*1000000 + BM*1000 + BN, e.g. 16128128 */
+    int tile;                                    /* 0 = auto; else [2000000000 +] BK*1000000 + BM*1000 + BN, e.g. 16128128;
+                                                    tiles 128x{32,64,128,192}, 64x64; BK 16 or 32; the 2e9 marker selects the
+                                                    paired-pipeline variant of the 64x64 / BK 32 tile (small grids) */
     int precision;                               /* OFX_PREC_FP32 (default, exact fp32 MFMA) or OFX_PREC_BF16X3 */
 } ofx_conv_desc;
 
