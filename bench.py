@@ -167,7 +167,7 @@ def pick_cpu_threads() -> int:
     return best
 
 
-def cpu_baseline(budget_s=12.0, max_pairs=3):
+def cpu_baseline(budget_s=15.0, max_pairs=24):   # a bounded sample: ~15-20 s of CPU work
     """The CPU oracle (port of the reference's path) on the host cores: flow + warp + mask per pair."""
     from oracle import mask_oracle, raft_oracle, warp_oracle
     threads = pick_cpu_threads()
