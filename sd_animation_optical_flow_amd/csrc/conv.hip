@@ -96,12 +96,13 @@ __global__ __launch_bounds__(256 * KS, (BK == 16 && KS == 1) ? 3 : 1) void igemm
     constexpr int LDK = BK + 4;               // LDS row stride in floats (144 B / 80 B): conflict-free b128 fragment reads
     constexpr int QPR = BK / 4;               // float4 slots per staged row
     constexpr int RPG = 256 / QPR;            // rows staged per pass of the 256 threads
-    constexpr int A_PER = BM / RPG, B_PER = BN / RPG;
-    static_assert(A_PER >= 1 && B_PER >= 1, "tile too small for this BK");
+    constexpr int A_PER = BM / RPG, B_PER = (BN + RPG - 1) / RPG;
+    constexpr int BN_ST = B_PER * RPG;        // B rows staged (> BN only for the 96-wide tile: the surplus rows are never read)
+    static_assert(A_PER >= 1 && BM % RPG == 0, "tile too small for this BK");
     // PREC = 1 (bf16x3): every fp32 operand element is staged as two bf16 values hi = bf16(x), lo = bf16(x - hi)
     // (same 4 bytes per element); rows are BK bf16 + 16 B of padding (48 B / 80 B: conflict-free b128 reads)
     constexpr int ROWB = BK * 2 + 16;                       // bytes per staged bf16 row
-    constexpr int STAGE = PREC ? ((BM + BN) * ROWB * 2) / 4 : (BM + BN) * LDK;   // floats per stage
+    constexpr int STAGE = PREC ? ((BM + BN_ST) * ROWB * 2) / 4 : (BM + BN_ST) * LDK;   // floats per stage
     static_assert((BM / WM) * (BN / WN) == 4, "4 waves per workgroup");
     static_assert(KS == 1 || KS == 2, "one or two pipelines");
     static_assert(KS == 1 || 2 * STAGE * KS >= 256 * TM * TN * 16, "accumulator exchange must fit the staging buffers");
@@ -296,7 +297,7 @@ __global__ __launch_bounds__(256 * KS, (BK == 16 && KS == 1) ? 3 : 1) void igemm
             char* a_hi = reinterpret_cast<char*>(stage);
             char* a_lo = a_hi + BM * ROWB;
             char* b_hi = a_lo + BM * ROWB;
-            char* b_lo = b_hi + BN * ROWB;
+            char* b_lo = b_hi + BN_ST * ROWB;
 #pragma unroll
             for (int i = 0; i < A_PER; ++i) {
                 const int o = (r0 + RPG * i) * ROWB + kq * 8;
@@ -350,7 +351,7 @@ __global__ __launch_bounds__(256 * KS, (BK == 16 && KS == 1) ? 3 : 1) void igemm
             const char* a_hi = reinterpret_cast<const char*>(smem + (kt & 1) * STAGE);
             const char* a_lo = a_hi + BM * ROWB;
             const char* b_hi = a_lo + BM * ROWB;
-            const char* b_lo = b_hi + BN * ROWB;
+            const char* b_lo = b_hi + BN_ST * ROWB;
 #pragma unroll
             for (int ks = 0; ks < BK / 16; ++ks) {
                 bf16x8 ah[TM], al[TM], bh[TN], bl[TN];
@@ -650,11 +651,13 @@ extern "C" int ofx_conv2d_alpha(const ofx_conv_desc* d, float alpha, void* strea
         if (d->Cout <= 32) bn = 32;
         else if (waste(128) <= 1.13) bn = 128;
         else if (waste(192) <= 1.05 && d->precision == OFX_PREC_FP32 && !d->nmean && d->epi != OFX_EPI_FLOW) bn = 192;   // 192-channel layers: one 128x192 tile instead of 128x64 x 3
+        else if (waste(96) <= 1.05 && d->precision == OFX_PREC_FP32 && d->epi == OFX_EPI_PLAIN) bn = 96;   // 96-channel encoder stage
         else if (waste(64) <= 1.13) bn = 64;
         else if (waste(32) < waste(64) - 0.1) bn = 32;
         else bn = 64;
         bm = 128;
         const long blocks128 = ((M + 127) / 128) * ((d->Cout + bn - 1) / bn) * nz;
+        if (bn == 96 && blocks128 < 1024) bn = 32;   // no small-grid variant of the 96-wide tile
         if (bn >= 64 && blocks128 < 1024) bm = 64;   // under ~4 waves of 256 CUs: smaller tiles fill the chip
         if (bm == 64 && bn >= 128) bn = 64;
     }
@@ -685,6 +688,7 @@ extern "C" int ofx_conv2d_alpha(const ofx_conv_desc* d, float alpha, void* strea
         if (bm == 64 && bn == 64) return launch_tile<64, 64, 32, 32, 16, 1>(k, d->epi, norm, nz, s);
     }
     if (bm == 128 && bn == 192) return launch_tile<128, 192, 64, 96, 16>(k, d->epi, norm, nz, s);
+    if (bm == 128 && bn == 96) return launch_tile<128, 96, 32, 96, 16>(k, d->epi, norm, nz, s);
     if (bm == 128 && bn == 128 && bk == 16) return launch_tile<128, 128, 64, 64, 16>(k, d->epi, norm, nz, s);
     if (bm == 128 && bn == 64 && bk == 16) return launch_tile<128, 64, 64, 32, 16>(k, d->epi, norm, nz, s);
     if (bm == 128 && bn == 128) return launch_tile<128, 128, 64, 64, 32>(k, d->epi, norm, nz, s);

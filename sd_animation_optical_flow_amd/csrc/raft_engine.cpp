@@ -62,7 +62,7 @@ constexpr int MOT_OFF = HD;
 constexpr int FLOW_OFF = MOT_OFF + 126;
 constexpr int INP_OFF = HD + 128;
 constexpr int GADD_LD = 2 * (2 * HD + HD);   // [zr1(256) | q1(128) | zr2(256) | q2(128)]
-constexpr int ENC_CHUNK = 16;          // images per encoder pass (bounds the activation workspace)
+constexpr int ENC_CHUNK = 64;          // images per encoder pass (bounds the activation workspace)
 // ... fewer for large frames: the widest encoder activation (64 channels at half resolution) must stay
 // below the 2 GiB reach of the convolution kernel's 32-bit byte offsets
 static inline int enc_chunk(int H, int W) {

@@ -62,6 +62,8 @@ CONV_CASES = [
     (1, 32, 32, 128, 128, 3, 3, 1, None, 32128128),
     (1, 32, 32, 128, 128, 3, 3, 1, None, 32128064),
     (2, 19, 23, 96, 192, 3, 3, 1, "relu", 16128192),         # 128x192 tile, ragged M (874 rows)
+    (2, 21, 19, 64, 96, 3, 3, 1, "relu", 16128096),          # 128x96 tile (B rows staged past the tile), ragged M
+    (1, 24, 24, 96, 200, 1, 1, 1, None, 16128096),           # ... three N tiles, ragged N
     (1, 20, 28, 96, 64, 3, 3, 1, None, 2032064064),          # paired K pipelines, odd chunk count (27), ragged M
     (1, 20, 28, 64, 128, 1, 1, 1, "relu", 2032064064),       # ... two chunks: one per pipeline
     (1, 8, 8, 32, 64, 1, 1, 1, None, 2032064064),            # ... one chunk: the second pipeline adds nothing
