@@ -73,6 +73,7 @@ struct ConvK {
 #ifndef OFX_SCHED
 #define OFX_SCHED 2
 #endif
+constexpr int kEpiPlainT = 4;   // internal: OFX_EPI_PLAIN with a sigmoid / tanh activation (own instantiation, own register budget)
 constexpr int kKAlign = 32;   // packed weights are zero-padded along K to this (a multiple of every BK)
 
 __device__ __forceinline__ float apply_act_rt(float v, int act) {
@@ -433,6 +434,23 @@ __global__ __launch_bounds__(256 * KS, (BK == 16 && KS == 1) ? 3 : 1) void igemm
     const int mb0 = m0 + wm * WM + 4 * (lane >> 5);       // first row of this thread
     const int lim = Mrows - mb0;                          // relative rows r < lim exist
     constexpr int EB = EPI == OFX_EPI_GRU_Q ? 4 : 8;
+    // Control flow is kept out of the element loops: the optional reads are decided once per batch of EB
+    // elements, ReLU / the residual ReLU are a max against 0 or -FLT_MAX, the transcendental activations of the
+    // plain epilogue are a separate instantiation (a per-element `switch (act)` compiled to ~20 branches per
+    // output and 80 KB of code; the epilogue then took as long as ten K-chunks).
+    // per-column scale / shift of all TN sub-tiles in one round trip (loaded inside the j loop they cost one
+    // dependent global-load latency per sub-tile: ~10 k cycles of a 24 k-cycle epilogue)
+    float scv[TN], shv[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int nn = min(n0 + wn * WN + j * 32 + (lane & 31), p.Cout - 1);
+        scv[j] = p.scale ? p.scale[nn] : 1.0f;
+        shv[j] = p.shift ? p.shift[nn] : 0.0f;
+    }
+    const float act_lo = p.act == OFX_ACT_RELU ? 0.0f : -3.402823466e38f;
+    const float res_lo = has_res ? 0.0f : -3.402823466e38f;
+    constexpr bool TRANSC = EPI == kEpiPlainT;            // plain epilogue with sigmoid / tanh
+    constexpr int EPK = TRANSC ? OFX_EPI_PLAIN : EPI;     // epilogue kind
     auto epilogue = [&](auto full_tag) {
         constexpr bool FULL = decltype(full_tag)::value;  // tile entirely inside M: no per-row masks
 #pragma unroll
@@ -440,11 +458,10 @@ __global__ __launch_bounds__(256 * KS, (BK == 16 && KS == 1) ? 3 : 1) void igemm
             const int nbase = n0 + wn * WN + j * 32;      // wave-uniform
             const int n = nbase + (lane & 31);
             const bool nok = n < p.Cout;
-            const int nn = min(n, p.Cout - 1);
             const int cmask = nok ? 0 : kOOB;
-            const float sc = p.scale ? p.scale[nn] * p.alpha : p.alpha;
-            const float sh = p.shift ? p.shift[nn] : 0.0f;
-            if constexpr (EPI == OFX_EPI_FLOW) {
+            const float sc = scv[j] * p.alpha;
+            const float sh = shv[j];
+            if constexpr (EPK == OFX_EPI_FLOW) {
                 // Cout = 2: a handful of lanes; plain pointer code
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
@@ -466,54 +483,70 @@ __global__ __launch_bounds__(256 * KS, (BK == 16 && KS == 1) ? 3 : 1) void igemm
             } else {
                 const int hd = p.Cout >> 1;
                 // the z | r split of the fused GRU gate conv is 32-aligned -> uniform per wave and j
-                const bool r_half = EPI == OFX_EPI_GRU_ZR && __builtin_amdgcn_readfirstlane(nbase) >= hd;
+                const bool r_half = EPK == OFX_EPI_GRU_ZR && __builtin_amdgcn_readfirstlane(nbase) >= hd;
                 const __amdgpu_buffer_rsrc_t rs_add = rsrc_of(p.addend, p.ldadd);
                 const int vo_add = ((mb0 * p.ldadd + n) * 4) | cmask;
                 // array 1 / array 2 read by this epilogue, array written
-                const void* p1 = EPI == OFX_EPI_PLAIN ? (const void*)p.res : EPI == OFX_EPI_GRU_ZR ? (const void*)p.aux_h : (const void*)p.aux_z;
-                const int ld1 = EPI == OFX_EPI_PLAIN ? p.ldres : EPI == OFX_EPI_GRU_ZR ? p.ldh : p.Cout;
-                const int c1 = EPI == OFX_EPI_GRU_ZR ? n - hd : n;
+                const void* p1 = EPK == OFX_EPI_PLAIN ? (const void*)p.res : EPK == OFX_EPI_GRU_ZR ? (const void*)p.aux_h : (const void*)p.aux_z;
+                const int ld1 = EPK == OFX_EPI_PLAIN ? p.ldres : EPK == OFX_EPI_GRU_ZR ? p.ldh : p.Cout;
+                const int c1 = EPK == OFX_EPI_GRU_ZR ? n - hd : n;
                 const __amdgpu_buffer_rsrc_t rs_1 = rsrc_of(p1, ld1);
                 const int vo_1 = ((mb0 * ld1 + c1) * 4) | cmask;
                 const __amdgpu_buffer_rsrc_t rs_h = rsrc_of(p.aux_h, p.ldh);          // GRU_Q: h read and written
                 const int vo_h = ((mb0 * p.ldh + n) * 4) | cmask;
-                const void* pw = EPI == OFX_EPI_PLAIN ? (void*)out : EPI == OFX_EPI_GRU_Q ? (void*)p.aux_h : r_half ? (void*)p.aux_rh : (void*)p.aux_z;
-                const int ldw = EPI == OFX_EPI_PLAIN ? p.ldo : EPI == OFX_EPI_GRU_Q ? p.ldh : hd;
-                const int cw = (EPI == OFX_EPI_GRU_ZR && r_half) ? n - hd : n;
+                const void* pw = EPK == OFX_EPI_PLAIN ? (void*)out : EPK == OFX_EPI_GRU_Q ? (void*)p.aux_h : r_half ? (void*)p.aux_rh : (void*)p.aux_z;
+                const int ldw = EPK == OFX_EPI_PLAIN ? p.ldo : EPK == OFX_EPI_GRU_Q ? p.ldh : hd;
+                const int cw = (EPK == OFX_EPI_GRU_ZR && r_half) ? n - hd : n;
                 const __amdgpu_buffer_rsrc_t rs_w = rsrc_of(pw, ldw);
                 const int vo_w = ((mb0 * ldw + cw) * 4) | cmask;
-                const bool need1 = EPI == OFX_EPI_PLAIN ? has_res : EPI == OFX_EPI_GRU_ZR ? r_half : true;
+                const bool need1 = EPK == OFX_EPI_PLAIN ? has_res : EPK == OFX_EPI_GRU_ZR ? r_half : true;
 #pragma unroll
                 for (int ib = 0; ib < TM * (16 / EB); ++ib) {
                     // EB elements per phase: enough loads in flight to cover the latency, few enough live
                     // registers to keep the kernel at three workgroups per CU
                     const int i = ib / (16 / EB), e0 = (ib % (16 / EB)) * EB;
                     float ad[EB], x1[EB], x2[EB];
+                    auto row_of = [&](int q) { const int e = e0 + q; return i * 32 + (e & 3) + 8 * (e >> 2); };
+                    auto mask_of = [&](int r) { return FULL ? 0 : (r < lim ? 0 : kOOB); };
+                    if (has_add) {
 #pragma unroll
-                    for (int q = 0; q < EB; ++q) {
-                        const int e = e0 + q;
-                        const int r = i * 32 + (e & 3) + 8 * (e >> 2);
-                        const int rmask = FULL ? 0 : (r < lim ? 0 : kOOB);
-                        ad[q] = has_add ? ldf(rs_add, vo_add | rmask, r * p.ldadd * 4) : 0.0f;
-                        x1[q] = need1 ? ldf(rs_1, vo_1 | rmask, r * ld1 * 4) : 0.0f;
-                        x2[q] = EPI == OFX_EPI_GRU_Q ? ldf(rs_h, vo_h | rmask, r * p.ldh * 4) : 0.0f;
+                        for (int q = 0; q < EB; ++q) ad[q] = ldf(rs_add, vo_add | mask_of(row_of(q)), row_of(q) * p.ldadd * 4);
+                    } else {
+#pragma unroll
+                        for (int q = 0; q < EB; ++q) ad[q] = 0.0f;
+                    }
+                    if (need1) {
+#pragma unroll
+                        for (int q = 0; q < EB; ++q) x1[q] = ldf(rs_1, vo_1 | mask_of(row_of(q)), row_of(q) * ld1 * 4);
+                    } else {
+#pragma unroll
+                        for (int q = 0; q < EB; ++q) x1[q] = EPK == OFX_EPI_GRU_ZR ? 1.0f : 0.0f;   // z half: no r*h product
+                    }
+#pragma unroll
+                    for (int q = 0; q < EB; ++q) x2[q] = EPK == OFX_EPI_GRU_Q ? ldf(rs_h, vo_h | mask_of(row_of(q)), row_of(q) * p.ldh * 4) : 0.0f;
+                    float v[EB];
+#pragma unroll
+                    for (int q = 0; q < EB; ++q) v[q] = acc[i][j][e0 + q] * sc + sh + ad[q];
+                    if (EPK == OFX_EPI_PLAIN && TRANSC) {
+                        if (p.act == OFX_ACT_SIGMOID) {
+#pragma unroll
+                            for (int q = 0; q < EB; ++q) v[q] = ofx_sigmoid(v[q]);
+                        } else {
+#pragma unroll
+                            for (int q = 0; q < EB; ++q) v[q] = ofx_tanh(v[q]);
+                        }
                     }
 #pragma unroll
                     for (int q = 0; q < EB; ++q) {
-                        const int e = e0 + q;
-                        const int r = i * 32 + (e & 3) + 8 * (e >> 2);
-                        const int rmask = FULL ? 0 : (r < lim ? 0 : kOOB);
-                        float v = acc[i][j][e] * sc + sh + ad[q];
-                        if (EPI == OFX_EPI_PLAIN) {
-                            v = apply_act_rt(v, p.act);
-                            if (has_res) v = fmaxf(v + x1[q], 0.f);
-                        } else if (EPI == OFX_EPI_GRU_ZR) {
-                            v = ofx_sigmoid(v);
-                            if (r_half) v *= x1[q];
+                        if (EPK == OFX_EPI_PLAIN) {
+                            if (!TRANSC) v[q] = fmaxf(v[q], act_lo);   // ReLU or identity
+                            v[q] = fmaxf(v[q] + x1[q], res_lo);        // residual merge: relu(y + res), or y (x1 = 0)
+                        } else if (EPK == OFX_EPI_GRU_ZR) {
+                            v[q] = ofx_sigmoid(v[q]) * x1[q];          // z, or r * h
                         } else {
-                            v = (1.0f - x1[q]) * x2[q] + x1[q] * ofx_tanh(v);
+                            v[q] = (1.0f - x1[q]) * x2[q] + x1[q] * ofx_tanh(v[q]);
                         }
-                        stf(v, rs_w, vo_w | rmask, r * ldw * 4);
+                        stf(v[q], rs_w, vo_w | mask_of(row_of(q)), row_of(q) * ldw * 4);
                     }
                 }
             }
@@ -529,8 +562,14 @@ int launch_tile(const ConvK& k, int epi, bool norm, int nz, hipStream_t s) {
     dim3 block(256 * KS, 1, 1);
     switch (epi) {
         case OFX_EPI_PLAIN:
-            if (norm) hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, OFX_EPI_PLAIN, true, BK, PREC, KS>), grid, block, 0, s, k);
-            else hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, OFX_EPI_PLAIN, false, BK, PREC, KS>), grid, block, 0, s, k);
+            if (k.act >= OFX_ACT_SIGMOID) {
+                if (norm) return OFX_EINVAL;   // fused-norm producer layers are followed by ReLU / identity only
+                hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, kEpiPlainT, false, BK, PREC, KS>), grid, block, 0, s, k);
+            } else if (norm) {
+                hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, OFX_EPI_PLAIN, true, BK, PREC, KS>), grid, block, 0, s, k);
+            } else {
+                hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, OFX_EPI_PLAIN, false, BK, PREC, KS>), grid, block, 0, s, k);
+            }
             break;
         case OFX_EPI_GRU_ZR: hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, OFX_EPI_GRU_ZR, false, BK, PREC, KS>), grid, block, 0, s, k); break;
         case OFX_EPI_GRU_Q: hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, OFX_EPI_GRU_Q, false, BK, PREC, KS>), grid, block, 0, s, k); break;
