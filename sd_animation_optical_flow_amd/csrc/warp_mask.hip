@@ -435,6 +435,113 @@ __global__ __launch_bounds__(256) void warp_u8c3_x4_kernel(const uint8_t* __rest
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// bilinear fast path (the bench / FrameSynthesizer default): uint8 x 3 channels, W % 4 == 0, everything
+// addressable with 32 bits.  Same arithmetic as warp_pixel (weights, products and sums in the same order,
+// contraction off) with the instruction count roughly halved -- the x4 kernel above spends ~200 VALU
+// instructions per pixel and is VALU-bound, not HBM-bound:
+//   * 32-bit index math, the (row, x-group) split by magic-number division;
+//   * out-of-image taps get a ZERO WEIGHT instead of a zeroed pixel (u8 * 0 = +0 either way), so the
+//     loaded bytes never need masking;
+//   * a row of two taps is one unaligned 8-byte load whose bytes are consumed directly by
+//     v_cvt_f32_ubyteN; channel pairs are blended with packed fp32 math.
+// ------------------------------------------------------------------------------------------
+struct BilinArgs {
+    const uint8_t* frame;
+    const float* flow;
+    uint8_t* out;
+    int H, W, W4;
+    unsigned fbs;            // bytes between key frames (0 = shared)
+    unsigned img_bytes;
+    unsigned ngroups;
+    unsigned magic_w4, magic_h;   // ceil(2^32 / d); exact for the operand ranges checked by the launcher
+    float sign;
+};
+
+typedef float ofx_v2f __attribute__((ext_vector_type(2)));
+
+__global__ __launch_bounds__(256) void warp_bilinear_u8c3_kernel(const BilinArgs a) {
+    // one group of 4 pixels per thread (the launcher sizes the grid to cover all groups): the kernel is bound by
+    // the two dependent memory latencies of a group (flow, then taps) times the generations of resident
+    // wavefronts, so more independent threads beat longer per-thread loops (a software-pipelined 4-groups-per-
+    // thread variant measured 23 % slower)
+    for (unsigned g = blockIdx.x * 256u + threadIdx.x; g < a.ngroups; g += gridDim.x * 256u) {
+        const float4 fa = reinterpret_cast<const float4*>(a.flow)[2 * (size_t)g];       // output pixel 4g -> float4 2g, 2g+1
+        const float4 fb = reinterpret_cast<const float4*>(a.flow)[2 * (size_t)g + 1];
+        const unsigned row = a.W4 == 1 ? g : __umulhi(g, a.magic_w4);      // b*H + y
+        const int x = (int)(g - row * (unsigned)a.W4) * 4;
+        const unsigned b = a.H == 1 ? row : __umulhi(row, a.magic_h);
+        const int y = (int)(row - b * (unsigned)a.H);
+        const unsigned p0 = row * (unsigned)a.W + (unsigned)x;               // first output pixel
+        const unsigned fbase = b * a.fbs;
+        const unsigned last8 = fbase + a.img_bytes - 8u;                      // last 8 readable bytes of this frame
+        const float fxs[4] = {fa.x, fa.z, fb.x, fb.z}, fys[4] = {fa.y, fa.w, fb.y, fb.w};
+        unsigned lo[4][2], hi[4][2];
+        unsigned eqx[4];
+        float w[4][4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float mx = map_coord(x + j, fxs[j], a.sign), my = map_coord(y, fys[j], a.sign);
+            const float x0f = floorf(mx), y0f = floorf(my);
+            const float fx = mx - x0f, fy = my - y0f;
+            const int x0 = (int)fminf(fmaxf(x0f, -1.0e6f), 1.0e6f);
+            const int y0 = (int)fminf(fmaxf(y0f, -1.0e6f), 1.0e6f);
+            const bool xa = (unsigned)x0 < (unsigned)a.W, xb = (unsigned)(x0 + 1) < (unsigned)a.W;
+            const bool ya = (unsigned)y0 < (unsigned)a.H, yb = (unsigned)(y0 + 1) < (unsigned)a.H;
+            const float gx = 1.f - fx, gy = 1.f - fy;
+            w[j][0] = (xa && ya) ? gx * gy : 0.f;
+            w[j][1] = (xb && ya) ? fx * gy : 0.f;
+            w[j][2] = (xa && yb) ? gx * fy : 0.f;
+            w[j][3] = (xb && yb) ? fx * fy : 0.f;
+            const int xc = min(max(x0, 0), a.W - 2);
+            eqx[j] = x0 == xc ? 1u : 0u;                                      // taps sit at bytes 0..5 in order
+#pragma unroll
+            for (int rr = 0; rr < 2; ++rr) {
+                const int yc = min(max(y0 + rr, 0), a.H - 1);
+                const unsigned off = fbase + (unsigned)(yc * a.W + xc) * 3u;
+                const unsigned start = min(off, last8);                       // the frame's last pixel pair: back up 2 bytes
+                const PackedU2 v = *reinterpret_cast<const PackedU2*>(a.frame + start);
+                const unsigned sh = off - start;                              // 0 or 2 bytes
+                lo[j][rr] = __builtin_amdgcn_alignbyte(v.b, v.a, sh);
+                hi[j][rr] = v.b >> (8u * sh);
+            }
+        }
+        unsigned res[4][3];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            unsigned t[4];                                                    // packed pixels of the 4 taps (low 3 bytes)
+#pragma unroll
+            for (int rr = 0; rr < 2; ++rr) {
+                const unsigned pa = lo[j][rr];
+                const unsigned pb = __builtin_amdgcn_alignbyte(hi[j][rr], lo[j][rr], 3u);
+                t[rr * 2 + 0] = eqx[j] ? pa : pb;
+                t[rr * 2 + 1] = eqx[j] ? pb : pa;
+            }
+            ofx_v2f acc01;
+            float acc2;
+            {
+                const ofx_v2f p = {(float)(t[0] & 0xFFu), (float)((t[0] >> 8) & 0xFFu)};
+                acc01 = p * w[j][0];
+                acc2 = (float)((t[0] >> 16) & 0xFFu) * w[j][0];
+            }
+#pragma unroll
+            for (int k = 1; k < 4; ++k) {
+                const ofx_v2f p = {(float)(t[k] & 0xFFu), (float)((t[k] >> 8) & 0xFFu)};
+                acc01 = acc01 + p * w[j][k];
+                acc2 = acc2 + (float)((t[k] >> 16) & 0xFFu) * w[j][k];
+            }
+            res[j][0] = (unsigned)fminf(fmaxf(rintf(acc01.x), 0.f), 255.f);
+            res[j][1] = (unsigned)fminf(fmaxf(rintf(acc01.y), 0.f), 255.f);
+            res[j][2] = (unsigned)fminf(fmaxf(rintf(acc2), 0.f), 255.f);
+        }
+        uint3 o;
+        o.x = res[0][0] | (res[0][1] << 8) | (res[0][2] << 16) | (res[1][0] << 24);
+        o.y = res[1][1] | (res[1][2] << 8) | (res[2][0] << 16) | (res[2][1] << 24);
+        o.z = res[2][2] | (res[3][0] << 8) | (res[3][1] << 16) | (res[3][2] << 24);
+        *reinterpret_cast<uint3*>(a.out + (size_t)p0 * 3) = o;                // p0 % 4 == 0 -> 4-byte aligned
+    }
+}
+
 template <typename T, int C>
 int launch_warp_c(const T* frame, long fbs, const float* flow, T* out, int B, int H, int W, int mode,
                   float sign, hipStream_t s) {
@@ -470,6 +577,26 @@ int launch_warp(const T* frame, long fbs, const float* flow, T* out, int B, int 
         if (st) return st;
     }
     hipStream_t s = (hipStream_t)stream;
+    const long npix = (long)B * H * W;
+    if (sizeof(T) == 1 && C == 3 && mode == OFX_WARP_BILINEAR && (W & 3) == 0 && H >= 2 && npix * 8 < (1L << 32) &&
+        (fbs == 0 || fbs == (long)H * W * 3) && (long)H * W * 3 >= 8 && (((uintptr_t)flow) & 15u) == 0 && (((uintptr_t)out) & 3u) == 0) {
+        BilinArgs a;
+        a.frame = (const uint8_t*)frame; a.flow = flow; a.out = (uint8_t*)out;
+        a.H = H; a.W = W; a.W4 = W >> 2;
+        a.fbs = (unsigned)fbs; a.img_bytes = (unsigned)((long)H * W * 3);
+        a.ngroups = (unsigned)(npix >> 2);
+        // umulhi(n, ceil(2^32 / d)) == n / d for n * d < 2^32 (n < ngroups <= 2^29 here, d <= 2^16 in practice;
+        // the bound is checked)
+        auto magic = [](unsigned d) { return (unsigned)(((1ull << 32) + d - 1) / d); };
+        a.magic_w4 = magic((unsigned)a.W4); a.magic_h = magic((unsigned)H);
+        a.sign = sign;
+        if ((unsigned long long)a.ngroups * (unsigned)a.W4 < (1ull << 32) && (unsigned long long)B * H * (unsigned)H < (1ull << 32)) {
+            const int grid = (int)std::min<long>(((long)a.ngroups + 255) / 256, 1L << 22);   // one group per thread
+            OfxProfScope prof("warp_u8", s);
+            hipLaunchKernelGGL(warp_bilinear_u8c3_kernel, dim3(grid), dim3(256), 0, s, a);
+            return ofx_launch_status();
+        }
+    }
     if (sizeof(T) == 1 && C == 3 && mode != OFX_WARP_BICUBIC && W >= 4 && H >= 2) {
         const long ngroups = (long)B * H * ((W + 3) / 4);
         const int grid = (int)std::min<long>((ngroups + 255) / 256, 256L * 64);
