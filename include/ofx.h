@@ -129,6 +129,7 @@ int ofx_warp_and_mask(const uint8_t* frame, long frame_bstride, const float* flo
  * with fp32 accumulation (operands carry ~16 mantissa bits; measured end-to-end flow EPE ~1e-4 px). */
 #define OFX_PREC_FP32   0
 #define OFX_PREC_BF16X3 1
+#define OFX_PREC_BF16X3_W 2   /* bf16x3 with `w` already in the split format of ofx_split_conv_weight */
 
 typedef struct ofx_conv_desc {
     /* input: NHWC fp32, up to two channel segments (torch.cat along C without materialising) */
@@ -158,6 +159,11 @@ int ofx_conv2d(const ofx_conv_desc* d, void* stream);
  * Returns Kpad (or negative error).  `out` may be NULL to query the size. */
 long ofx_pack_conv_weight(const float* w_oihw, int Cout, int Cin, int KH, int KW, int cin_pad,
                           float* out);
+/* Host-side: packed fp32 weights [n_floats] (n_floats % 4 == 0) -> the pre-split bf16x3 operand format: every
+ * group of four consecutive k becomes 16 bytes [hi0 hi1 hi2 hi3 | lo0 lo1 lo2 lo3] with hi = bf16(x),
+ * lo = bf16(x - hi), both round-to-nearest-even -- bit-identical to what the kernel's on-the-fly split makes.
+ * Same size as the input; use with precision = OFX_PREC_BF16X3_W. Returns 0 or OFX_EINVAL. */
+int ofx_split_conv_weight(const float* packed, long n_floats, float* out);
 
 /* instance norm statistics over HW per (b,c): mean and 1/sqrt(var+eps) (biased var), NHWC input */
 int ofx_inorm_stats(const float* x, int ld, float* mean, float* rstd, float* scratch,

@@ -38,6 +38,7 @@
 #include "ofx_internal.h"
 
 #include <algorithm>
+#include <cstring>
 #include <type_traits>
 
 namespace {
@@ -304,8 +305,17 @@ __global__ __launch_bounds__(256 * KS, (BK == 16 && KS == 1) ? 3 : 1) void igemm
                 const int o = (r0 + RPG * i) * ROWB + kq * 8;
                 split_store(a_hi + o, a_lo + o, norm_a(i));
             }
+            // PREC = 2: the weight matrix arrives pre-split ([hi x4 | lo x4] per 16 bytes): two 8-byte copies, no VALU
 #define OFX_B_COMMIT(i) \
-    if constexpr (B_PER > i) { const int o = (r0 + RPG * i) * ROWB + kq * 8; split_store(b_hi + o, b_lo + o, rb##i); }
+    if constexpr (B_PER > i) { \
+        const int o = (r0 + RPG * i) * ROWB + kq * 8; \
+        if constexpr (PREC == 2) { \
+            *reinterpret_cast<float2*>(b_hi + o) = make_float2(rb##i.x, rb##i.y); \
+            *reinterpret_cast<float2*>(b_lo + o) = make_float2(rb##i.z, rb##i.w); \
+        } else { \
+            split_store(b_hi + o, b_lo + o, rb##i); \
+        } \
+    }
             OFX_B_COMMIT(0) OFX_B_COMMIT(1) OFX_B_COMMIT(2) OFX_B_COMMIT(3)
 #undef OFX_B_COMMIT
         }
@@ -719,12 +729,19 @@ extern "C" int ofx_conv2d_alpha(const ofx_conv_desc* d, float alpha, void* strea
     // chunk wins (+8..20 % at one 512x768 pair).  tile = BK*1e6 + BM*1e3 + BN overrides.
     const int tile_bk = (d->tile % 1000000000) / 1000000;
     const int bk = tile_bk ? tile_bk : ((bn == 32 || bm == 64) ? 32 : 16);
-    if (d->precision == OFX_PREC_BF16X3) {
-        // split-bf16 matrix-core path (opt-in): the three tiles below; anything else falls through to fp32
-        if (bm == 128 && bn == 128 && tile_bk == 32) return launch_tile<128, 128, 64, 64, 32, 1>(k, d->epi, norm, nz, s);
-        if (bm == 128 && bn == 128) return launch_tile<128, 128, 64, 64, 16, 1>(k, d->epi, norm, nz, s);
-        if (bm == 128 && bn == 64) return launch_tile<128, 64, 64, 32, 16, 1>(k, d->epi, norm, nz, s);
-        if (bm == 64 && bn == 64) return launch_tile<64, 64, 32, 32, 16, 1>(k, d->epi, norm, nz, s);
+    if (d->precision != OFX_PREC_FP32) {
+        // split-bf16 matrix-core path (opt-in): three tiles; every other choice is mapped onto them (the ragged
+        // N of a 96- or 2-channel layer is zero-filled by the descriptors)
+        if (bm == 64) bn = 64;
+        else if (bn != 64) bn = 128;
+        k.ntiles = (d->Cout + bn - 1) / bn;
+        k.group_m = k.ntiles >= 8 ? 8 : 1;
+        const bool wsplit = d->precision == OFX_PREC_BF16X3_W;
+        if (bm == 128 && bn == 128 && tile_bk == 32 && !wsplit) return launch_tile<128, 128, 64, 64, 32, 1>(k, d->epi, norm, nz, s);
+        if (bm == 128 && bn == 128) return wsplit ? launch_tile<128, 128, 64, 64, 16, 2>(k, d->epi, norm, nz, s) : launch_tile<128, 128, 64, 64, 16, 1>(k, d->epi, norm, nz, s);
+        if (bm == 128 && bn == 64) return wsplit ? launch_tile<128, 64, 64, 32, 16, 2>(k, d->epi, norm, nz, s) : launch_tile<128, 64, 64, 32, 16, 1>(k, d->epi, norm, nz, s);
+        if (bm == 64 && bn == 64) return wsplit ? launch_tile<64, 64, 32, 32, 16, 2>(k, d->epi, norm, nz, s) : launch_tile<64, 64, 32, 32, 16, 1>(k, d->epi, norm, nz, s);
+        return OFX_EINVAL;
     }
     if (bm == 128 && bn == 192) return launch_tile<128, 192, 64, 96, 16>(k, d->epi, norm, nz, s);
     if (bm == 128 && bn == 96) return launch_tile<128, 96, 32, 96, 16>(k, d->epi, norm, nz, s);
@@ -740,6 +757,35 @@ extern "C" int ofx_conv2d_alpha(const ofx_conv_desc* d, float alpha, void* strea
     if (bm == 64 && bn == 64 && pair) return launch_tile<64, 64, 32, 32, 32, 0, 2>(k, d->epi, norm, nz, s);
     if (bm == 64 && bn == 64) return launch_tile<64, 64, 32, 32, 32>(k, d->epi, norm, nz, s);
     return OFX_EINVAL;
+}
+
+namespace {
+inline uint16_t bf16_rne(float f) {
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    if ((u & 0x7FFFFFFFu) > 0x7F800000u) return (uint16_t)((u >> 16) | 0x40u);   // NaN stays NaN
+    return (uint16_t)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);
+}
+inline float bf16_to_f32(uint16_t h) {
+    const uint32_t u = (uint32_t)h << 16;
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+}
+}  // namespace
+
+extern "C" int ofx_split_conv_weight(const float* packed, long n, float* out) {
+    if (!packed || !out || n <= 0 || (n & 3)) return OFX_EINVAL;
+    uint16_t* o = reinterpret_cast<uint16_t*>(out);
+    for (long g = 0; g < n; g += 4)
+        for (int i = 0; i < 4; ++i) {
+            const float x = packed[g + i];
+            const uint16_t hi = bf16_rne(x);
+            const volatile float rem = x - bf16_to_f32(hi);       // exact in fp32; volatile: no contraction / reassociation
+            o[2 * g + i] = hi;
+            o[2 * g + 4 + i] = bf16_rne(rem);
+        }
+    return 0;
 }
 
 extern "C" long ofx_pack_conv_weight(const float* w, int Cout, int Cin, int KH, int KW, int cin_pad, float* out) {

@@ -30,6 +30,7 @@ namespace {
 
 struct ConvW {
     float* w = nullptr;       // [Cout][Kpad]
+    float* wsplit = nullptr;  // the same matrix pre-split into bf16 (hi, lo) quads for the bf16x3 mode
     float* scale = nullptr;   // [Cout] or null
     float* shift = nullptr;   // [Cout] or null
     int cout = 0, cin = 0, cin_pad = 0, kh = 0, kw = 0;
@@ -111,6 +112,16 @@ int upload(ofx_raft* r, const std::vector<float>& h, float** d) {
     return 0;
 }
 
+// both operand formats of a packed weight matrix: fp32, and the bf16x3 pre-split copy
+int upload_weight(ofx_raft* r, const std::vector<float>& packed, ConvW* c) {
+    int st = upload(r, packed, &c->w);
+    if (st) return st;
+    std::vector<float> sp(packed.size());
+    st = ofx_split_conv_weight(packed.data(), (long)packed.size(), sp.data());
+    if (st) return st;
+    return upload(r, sp, &c->wsplit);
+}
+
 const HostTensor* find(const std::map<std::string, HostTensor>& sd, const std::string& k) {
     auto it = sd.find(k);
     return it == sd.end() ? nullptr : &it->second;
@@ -189,7 +200,7 @@ int add_conv(ofx_raft* r, const std::map<std::string, HostTensor>& sd, const std
         r->convs[store_as] = c;
         return 0;
     }
-    int st = upload(r, pw, &c.w);
+    int st = upload_weight(r, pw, &c);
     if (st) return st;
     st = upload(r, shift, &c.shift);
     if (st) return st;
@@ -244,7 +255,7 @@ int build_gru(ofx_raft* r, const std::map<std::string, HostTensor>& sd, const st
         if (st) return st;
         ConvW c = r->convs["gru.z" + tag + sfx];
         c.cout *= 2;
-        st = upload(r, w, &c.w);
+        st = upload_weight(r, w, &c);
         if (st) return st;
         if (bias) {
             st = upload(r, sh, &c.shift);
@@ -275,7 +286,8 @@ struct Launcher {
         d.in0 = in0; d.ld0 = ld0; d.c0 = c0;
         d.in1 = in1; d.ld1 = ld1; d.c1 = c1;
         const int cout = rows ? rows : c.cout;
-        d.w = c.w + (long)row_off * c.kpad;
+        const bool wsplit = precision == OFX_PREC_BF16X3 && c.wsplit != nullptr;
+        d.w = (wsplit ? c.wsplit : c.w) + (long)row_off * c.kpad;
         d.scale = c.scale ? c.scale + row_off : nullptr;
         d.shift = c.shift ? c.shift + row_off : nullptr;
         d.out = out; d.ldo = ldo;
@@ -291,7 +303,7 @@ struct Launcher {
         d.Wout = (Win + 2 * padW - c.kw) / stride + 1;
         d.Cout = cout; d.KH = c.kh; d.KW = c.kw; d.stride = stride; d.padH = padH; d.padW = padW;
         d.act = act; d.epi = epi;
-        d.precision = precision;
+        d.precision = wsplit ? OFX_PREC_BF16X3_W : precision;
         if (c0 + c1 != c.cin_pad) { st = OFX_EKEY; return; }
         ofx_prof_set_tag(c.name.c_str());
         st = ofx_conv2d(&d, s);

@@ -227,6 +227,15 @@ def pack_conv_weight(w_oihw: torch.Tensor, cin_pad: Optional[int] = None) -> tor
     return out
 
 
+def split_conv_weight(w_packed: torch.Tensor) -> torch.Tensor:
+    """Packed fp32 weights (CPU) -> the pre-split bf16x3 operand format (same shape, fp32 container); feed it to
+    conv2d_nhwc(..., precision="bf16x3_w")."""
+    w = w_packed.detach().to(torch.float32).contiguous().cpu()
+    out = torch.empty_like(w)
+    check(_lib.lib().ofx_split_conv_weight(C.c_void_p(w.data_ptr()), w.numel(), C.c_void_p(out.data_ptr())), "ofx_split_conv_weight")
+    return out
+
+
 def conv2d_nhwc(x: torch.Tensor, w_packed: torch.Tensor, kh: int, kw: int, cout: int, *, stride: int = 1,
                 shift: Optional[torch.Tensor] = None, scale: Optional[torch.Tensor] = None, act: Optional[str] = None,
                 x2: Optional[torch.Tensor] = None, res: Optional[torch.Tensor] = None,
@@ -258,7 +267,7 @@ def conv2d_nhwc(x: torch.Tensor, w_packed: torch.Tensor, kh: int, kw: int, cout:
     d.B, d.Hin, d.Win, d.Hout, d.Wout, d.Cout = B, H, W, Ho, Wo, cout
     d.KH, d.KW, d.stride, d.padH, d.padW = kh, kw, stride, ph, pw
     d.act, d.epi, d.tile = ACTS[act], EPI_PLAIN, tile
-    d.precision = {"fp32": 0, "bf16x3": 1}[precision]
+    d.precision = {"fp32": 0, "bf16x3": 1, "bf16x3_w": 2}[precision]   # bf16x3_w: weight from split_conv_weight
     check(_lib.lib().ofx_conv2d(C.byref(d), _stream()), "ofx_conv2d")
     return out
 

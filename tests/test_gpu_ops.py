@@ -105,6 +105,10 @@ def test_conv2d_bf16x3_mode(cuda, case):
     e16 = (nchw(out16) - ref).abs().max().item()
     assert e32 < 2e-5 and e16 < 2e-4, (e32, e16)          # outputs are O(1): 16-bit operands -> ~1e-5 .. 1e-4
     assert e16 > 0                                           # and it really is a different arithmetic
+    # pre-split weights (what the executor uploads once): same hi / lo values -> bit-identical to the on-the-fly split
+    outw = ops.conv2d_nhwc(nhwc(x), ops.split_conv_weight(wp.cpu()).cuda(), kh, kw, co, stride=stride, shift=b.cuda(),
+                           precision="bf16x3_w")
+    assert torch.equal(outw, out16)
 
 
 def test_conv2d_two_segments_residual_and_scale(cuda):
