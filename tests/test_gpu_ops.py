@@ -156,6 +156,12 @@ def test_conv2d_padded_cin_and_fused_instance_norm(cuda):
     ref2 = F.conv2d(yref, w2, None, padding=1)
     out2 = ops.conv2d_nhwc(raw, ops.pack_conv_weight(w2).cuda(), 3, 3, 64, nmean=mean, nrstd=rstd)
     assert (nchw(out2) - ref2).abs().max().item() < 5e-5
+    # ... in every tile variant that has a fused-norm instantiation (the executor picks them by problem size)
+    w3 = torch.randn((96, 64, 3, 3), generator=g) / 24
+    ref3 = F.conv2d(yref, w3, None, padding=1)
+    for tile in (16128096, 16128128, 16128064, 32128032, 16064064, 2032064064):
+        out3 = ops.conv2d_nhwc(raw, ops.pack_conv_weight(w3).cuda(), 3, 3, 96, nmean=mean, nrstd=rstd, tile=tile)
+        assert (nchw(out3) - ref3).abs().max().item() < 5e-5, tile
     # residual merge with a normalised shortcut
     r = torch.randn(ref.shape, generator=g)
     rm, rs = ops.inorm_stats(nhwc(r))

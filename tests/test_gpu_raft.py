@@ -145,15 +145,19 @@ def test_non_multiple_of_8_is_padded_like_input_padder(engine, raft_sd):
     assert _epe(up[0].cpu(), torch.from_numpy(ref)) < 1e-3
 
 
-def test_batch_consistency_512x768(engine):
+@pytest.mark.parametrize("B", [3, 24])
+def test_batch_consistency_512x768(engine, B):
     """Full BASELINE size: a pair's flow must not depend on its batch neighbours or position
-    (each pair is an independent unit -- the property frame-parallel sharding relies on)."""
-    H, W, B = 768, 512, 3
+    (each pair is an independent unit -- the property frame-parallel sharding relies on).  B = 24 also crosses
+    the launcher's tile thresholds: the batch runs the 128x128 / 128x192 / 128x96 tiles and their GRU epilogues,
+    the single pair the 64x64 paired-pipeline tiles that the oracle tests validate -- the two must agree."""
+    H, W = 768, 512
     key, frames = _frames(6, B, H, W)
     up = engine.forward(frames.cuda(), key.cuda(), iters=3)
-    single = engine.forward(frames[1:2].cuda(), key.cuda(), iters=3)
     assert torch.isfinite(up).all()
-    assert (up[1:2] - single).abs().max().item() < 1e-4
+    for b in sorted({1, B - 1}):
+        single = engine.forward(frames[b:b + 1].cuda(), key.cuda(), iters=3)
+        assert (up[b:b + 1] - single).abs().max().item() < 1e-4, b
 
 
 def test_small_batch_stream_overlap_is_bit_identical_to_serial(engine):
