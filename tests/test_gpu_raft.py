@@ -99,6 +99,15 @@ def test_config_c1_256x384_pair(engine, raft_sd):
     assert _epe(up.cpu(), up_ref) < 1e-3
 
 
+def test_headline_size_512x768_pair_against_the_oracle(engine, raft_sd):
+    """The bench workload's frame size, 20 iterations, one pair: EPE against the CPU oracle (about a second of CPU)."""
+    H, W = 768, 512
+    key, frames = _frames(8, 1, H, W)
+    _, up_ref = _oracle_flow(raft_sd, frames, key[None], 20)
+    up = engine.forward(frames.cuda(), key.cuda(), iters=20)
+    assert _epe(up.cpu(), up_ref) < 1e-3
+
+
 def test_alternate_corr_engine_path(engine, raft_sd):
     H, W, B = 128, 128, 2
     key, frames = _frames(4, B, H, W)
