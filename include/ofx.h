@@ -112,6 +112,28 @@ int ofx_warp_and_mask(const uint8_t* frame, long frame_bstride, const float* flo
                       uint8_t* warped, uint8_t* mask, int B, int H, int W, int C, int warp_mode,
                       float sign, float thres, int ksize, int cmp_gt, void* stream);
 
+/* ---------------------------------------------------------------- SD-inpaint hand-off */
+/* What img2img_inpaint derives from (frame, reference, mask) before its first VAE call
+ * (ofgen_keyframe_inpaint.py:255-290 -> guided_ldm_inpainting.py:290-316,139-154), bit-exact to Pillow:
+ * PIL.ImageFilter.GaussianBlur(radius) on an 8-bit single-channel image [B,H,W] (BoxBlur.c: three extended-box
+ * passes per axis).  scratch: B*H*W bytes, distinct from in / out; in == out is allowed. */
+int ofx_gaussian_blur_u8(const uint8_t* in, uint8_t* out, uint8_t* scratch, int B, int H, int W, float radius,
+                         void* stream);
+/* PIL Image.resize((Wout, Hout)) with the default BICUBIC resample on an 8-bit channel (Resample.c: antialiased
+ * support, 22-bit fixed-point taps, horizontal pass to 8 bits then vertical).  scratch: B*Hin*Wout bytes. */
+int ofx_resize_bicubic_u8(const uint8_t* in, uint8_t* out, uint8_t* scratch, int B, int Hin, int Win, int Hout,
+                          int Wout, void* stream);
+/* image_bgr / reference_bgr u8[B,H,W,3] (cv2 order), image_mask u8[B,H,W] = the blurred mask, mask_latent
+ * u8[B,h,w] = the blurred mask resized to the latent grid.  Writes
+ *   image            f32[B,3,H,W]  RGB planar: Image.composite(reference, image, image_mask) / 127.5 - 1
+ *   cond_mask        f32[B,H,W]    round(image_mask / 255)
+ *   cond_image       f32[B,3,H,W]  image * (1 - cond_mask)
+ *   latmask          f32[B,4,h,w]  around(mask_latent / 255), tiled over the 4 latent channels
+ *   cond_mask_latent f32[B,h,w]    nearest-neighbour resize of cond_mask (F.interpolate default) */
+int ofx_sd_handoff(const uint8_t* image_bgr, const uint8_t* reference_bgr, const uint8_t* image_mask,
+                   const uint8_t* mask_latent, float* image, float* cond_image, float* cond_mask, float* latmask,
+                   float* cond_mask_latent, int B, int H, int W, int h, int w, void* stream);
+
 /* ---------------------------------------------------------------- implicit-GEMM conv */
 #define OFX_ACT_NONE    0
 #define OFX_ACT_RELU    1

@@ -360,3 +360,48 @@ def upsample_flow(coords1: torch.Tensor, mask: torch.Tensor) -> torch.Tensor:
     out = torch.empty((B, 8 * h, 8 * w, 2), dtype=torch.float32, device=c.device)
     check(_lib.lib().ofx_upsample_flow(_ptr(c), _ptr(m), _ptr(out), B, h, w, _stream()), "ofx_upsample_flow")
     return out
+
+
+# --------------------------------------------------------------------------------------
+# SD-inpaint hand-off: Pillow-exact mask blur / resize, composite + conditioning tensors
+# --------------------------------------------------------------------------------------
+def gaussian_blur_u8(mask: torch.Tensor, radius: float) -> torch.Tensor:
+    """uint8 [B,H,W] -> PIL.ImageFilter.GaussianBlur(radius) of every [H,W] plane."""
+    m = _chk(mask, "mask", torch.uint8)
+    B, H, W = m.shape
+    out = torch.empty_like(m)
+    scratch = torch.empty_like(m)
+    check(_lib.lib().ofx_gaussian_blur_u8(_ptr(m), _ptr(out), _ptr(scratch), B, H, W, float(radius), _stream()), "ofx_gaussian_blur_u8")
+    return out
+
+
+def resize_bicubic_u8(img: torch.Tensor, out_h: int, out_w: int) -> torch.Tensor:
+    """uint8 [B,H,W] -> PIL Image.resize((out_w, out_h)) (default BICUBIC resample) of every plane."""
+    m = _chk(img, "img", torch.uint8)
+    B, H, W = m.shape
+    out = torch.empty((B, out_h, out_w), dtype=torch.uint8, device=m.device)
+    scratch = torch.empty((B, H, out_w), dtype=torch.uint8, device=m.device)
+    check(_lib.lib().ofx_resize_bicubic_u8(_ptr(m), _ptr(out), _ptr(scratch), B, H, W, int(out_h), int(out_w), _stream()),
+          "ofx_resize_bicubic_u8")
+    return out
+
+
+def sd_handoff(image_bgr: torch.Tensor, reference_bgr: torch.Tensor, image_mask: torch.Tensor, mask_latent: torch.Tensor):
+    """See ofx_sd_handoff in include/ofx.h.  Returns (image, cond_image, cond_mask, latmask, cond_mask_latent)."""
+    a = _chk(image_bgr, "image_bgr", torch.uint8)
+    r = _chk(reference_bgr, "reference_bgr", torch.uint8)
+    m = _chk(image_mask, "image_mask", torch.uint8)
+    ml = _chk(mask_latent, "mask_latent", torch.uint8)
+    B, H, W, c3 = a.shape
+    if c3 != 3 or tuple(r.shape) != tuple(a.shape) or tuple(m.shape) != (B, H, W) or ml.dim() != 3 or ml.shape[0] != B:
+        raise RuntimeError("sd_handoff: shapes must be image/reference [B,H,W,3], image_mask [B,H,W], mask_latent [B,h,w]")
+    h, w = ml.shape[1:]
+    dev = a.device
+    image = torch.empty((B, 3, H, W), dtype=torch.float32, device=dev)
+    cond_image = torch.empty_like(image)
+    cond_mask = torch.empty((B, H, W), dtype=torch.float32, device=dev)
+    latmask = torch.empty((B, 4, h, w), dtype=torch.float32, device=dev)
+    cml = torch.empty((B, h, w), dtype=torch.float32, device=dev)
+    check(_lib.lib().ofx_sd_handoff(_ptr(a), _ptr(r), _ptr(m), _ptr(ml), _ptr(image), _ptr(cond_image), _ptr(cond_mask), _ptr(latmask),
+                                    _ptr(cml), B, H, W, h, w, _stream()), "ofx_sd_handoff")
+    return image, cond_image, cond_mask, latmask, cml

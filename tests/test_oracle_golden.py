@@ -154,3 +154,33 @@ def test_compose_single_reference_reduces_to_threshold_mask():
     ret, mask2, order = MO.compose(fm, [ai], orig, 0.5, warp_mode="bilinear")
     assert order == [0] and np.array_equal(ret, ai)   # zero flow: the warp is the identity
     assert np.array_equal(mask2, np.where(fm[0, 0, :, :, 2] > 0.5, 0, 255).astype(np.uint8))
+
+
+def test_sd_handoff_primitives_match_pillow_vectors():
+    """GaussianBlur / composite / default-resample resize: outputs of the real Pillow (make_golden_handoff.py),
+    bit for bit; plus a live comparison when Pillow is importable here."""
+    from oracle import handoff_oracle as HO
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "sd_handoff_pil.npz"))
+    for name in "abcd":
+        mask, blur = g[f"{name}_mask"], float(g[f"{name}_blur"])
+        H, W = mask.shape
+        b = HO.gaussian_blur_u8(mask, blur)
+        assert np.array_equal(b, g[f"{name}_pil_blur"]), name
+        assert np.array_equal(HO.composite(g[f"{name}_reference_rgb"], g[f"{name}_image_rgb"], b), g[f"{name}_pil_composite"]), name
+        assert np.array_equal(HO.resize_bicubic_u8(b, H // 8, W // 8), g[f"{name}_pil_latent"]), name
+    # the assembled hand-off: shapes, value sets and the identities the consumer relies on
+    r = HO.sd_handoff(g["a_image_rgb"][..., ::-1], g["a_reference_rgb"][..., ::-1], g["a_mask"], 4.0)
+    H, W = g["a_mask"].shape
+    assert r["image"].shape == (3, H, W) and r["latmask"].shape == (4, H // 8, W // 8)
+    assert np.array_equal(r["image"], np.moveaxis(g["a_pil_composite"].astype(np.float32) / 127.5 - 1.0, 2, 0))
+    assert set(np.unique(r["latmask"])) <= {0.0, 1.0} and set(np.unique(r["cond_mask"])) <= {0.0, 1.0}
+    assert np.array_equal(r["cond_mask"], (g["a_pil_blur"] >= 128).astype(np.float32))      # round(v/255), no ties on uint8
+    assert np.array_equal(r["cond_image"], r["image"] * (1 - r["cond_mask"])[None])
+    try:
+        from PIL import Image, ImageFilter
+    except ImportError:
+        return
+    rng = np.random.default_rng(9)
+    m = (rng.random((40, 56)) < 0.4).astype(np.uint8) * 255
+    for radius in (1, 3, 4, 6.5):
+        assert np.array_equal(HO.gaussian_blur_u8(m, radius), np.array(Image.fromarray(m).filter(ImageFilter.GaussianBlur(radius))))
