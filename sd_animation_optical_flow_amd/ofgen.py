@@ -201,7 +201,17 @@ class PDCNetAux:
     """ofgen_keyframe_inpaint.py:549-653.  `video` needs `.size_hw` and `.get_raw_frame(i) -> BGR uint8`;
     index containers need `.indices` and `__len__` (the reference's VideoData / VideoFrameIndices)."""
 
-    def __init__(self, pdcnet_model, workspace_dir: str, batch_size: int = 16, device=torch.device("cuda:0")) -> None:
+    def __init__(self, pdcnet_model, workspace_dir: str, batch_size: int = 16, device=torch.device("cuda:0"),
+                 async_save: bool = False) -> None:
+        """async_save=True (extension): the 4.7 MB-per-pair `.npy` dumps are written by a background
+        thread from a private copy, so they leave the caller's critical path; `flush()` (also called by
+        `load_cached`, `purge` and on deletion) waits for them.  Default: written before the call returns, like
+        the reference (:600)."""
+        self._pool = None
+        self._pending = []
+        if async_save:
+            from concurrent.futures import ThreadPoolExecutor
+            self._pool = ThreadPoolExecutor(max_workers=2, thread_name_prefix="ofx-npy")
         self.workspace_dir = workspace_dir
         self.cached_pair = set()
         self.batch_size = batch_size
@@ -216,13 +226,36 @@ class PDCNetAux:
         else:
             os.makedirs(self.pair_dir, exist_ok=True)
 
+    def _save(self, s: int, t: int, arr: np.ndarray) -> None:
+        path = os.path.join(self.pair_dir, f"{s:05d}-{t:05d}.npy")
+        if self._pool is None:
+            np.save(path, arr)
+        else:
+            self._pending.append(self._pool.submit(np.save, path, np.array(arr, copy=True)))   # callers mutate `ret` (:995)
+
+    def flush(self) -> None:
+        """Wait for queued `.npy` writes (no-op in the default synchronous mode); re-raises a failed write."""
+        pending, self._pending = self._pending, []
+        for f in pending:
+            f.result()
+
+    def __del__(self):
+        try:
+            self.flush()
+            if self._pool is not None:
+                self._pool.shutdown(wait=True)
+        except Exception:
+            pass
+
     def purge(self):
+        self.flush()
         self.cached_pair = set()
         for f in glob.glob(os.path.join(self.pair_dir, "*.npy")):
             os.remove(f)
 
     def load_cached(self, s, t):
         assert (s, t) in self.cached_pair
+        self.flush()
         return np.load(os.path.join(self.pair_dir, f"{s:05d}-{t:05d}.npy"))
 
     def calcualte_single(self, video, s, t):          # (sic) the reference's spelling, :576
@@ -248,7 +281,7 @@ class PDCNetAux:
                 si, ti = s2i_map[s], t2i_map[t]
                 ret[si, ti, :, :, 0:2] = flow[i]
                 ret[si, ti, :, :, 2] = conf[i]
-                np.save(os.path.join(self.pair_dir, f"{s:05d}-{t:05d}.npy"), ret[si, ti])
+                self._save(s, t, ret[si, ti])
             return
         for pair_batch in chunks(to_calculate_pairs, self.batch_size):
             bs = len(pair_batch)
@@ -263,7 +296,7 @@ class PDCNetAux:
                 si, ti = s2i_map[s], t2i_map[t]
                 ret[si, ti, :, :, 0:2] = flow_est[i]
                 ret[si, ti, :, :, 2] = confidence[i]
-                np.save(os.path.join(self.pair_dir, f"{s:05d}-{t:05d}.npy"), ret[si, ti])
+                self._save(s, t, ret[si, ti])
 
     def calculate_multiple_to_one(self, video, source_indices, target_index: int) -> np.ndarray:
         """-> f32[N, 1, H, W, 3] (:602-625)."""

@@ -179,6 +179,14 @@ def test_pdcnet_aux_pair_cache(algo, tmp_path):
     assert pw.shape == (2, 2, 64, 64, 3) and np.array_equal(pw[0, 1], on_disk)
     scores = aux2.keyframe_scores(pw)
     assert np.allclose(scores, MO.keyframe_scores(pw), rtol=1e-6)
+    # background writer: same files, available after flush(); the private copy survives the caller mutating `mat`
+    aux3 = ofgen.PDCNetAux(algo, str(tmp_path / "async"), batch_size=2, async_save=True)
+    mat3 = aux3.calculate_multiple_to_one(video, _Idx([0, 2, 1]), 1)
+    assert np.array_equal(mat3, mat)
+    mat3[:] = -1.0
+    aux3.flush()
+    assert np.array_equal(np.load(tmp_path / "async" / "pdcnet" / "00000-00001.npy"), on_disk)
+    assert np.array_equal(aux3.load_cached(2, 1), mat[1, 0])
 
 
 def test_frame_synthesizer_and_process_clip_device_path(algo, raft_sd):
