@@ -71,20 +71,8 @@ struct ConvK {
     int bytes0, bytes1, bytesw;     // extents of the two input segments and of the weight matrix (per z)
 };
 
-#ifndef OFX_SCHED
-#define OFX_SCHED 2
-#endif
 constexpr int kEpiPlainT = 4;   // internal: OFX_EPI_PLAIN with a sigmoid / tanh activation (own instantiation, own register budget)
 constexpr int kKAlign = 32;   // packed weights are zero-padded along K to this (a multiple of every BK)
-
-__device__ __forceinline__ float apply_act_rt(float v, int act) {
-    switch (act) {
-        case OFX_ACT_RELU: return fmaxf(v, 0.0f);
-        case OFX_ACT_SIGMOID: return ofx_sigmoid(v);
-        case OFX_ACT_TANH: return ofx_tanh(v);
-        default: return v;
-    }
-}
 
 // KS = 2 ("paired pipelines", small grids only): the workgroup has a second set of four waves that runs the
 // same pipeline on its own LDS buffers over the odd K chunks while the first set takes the even ones; the
@@ -394,9 +382,7 @@ __global__ __launch_bounds__(256 * KS, (BK == 16 && KS == 1) ? 3 : 1) void igemm
         commit(smem + ((kt + 1) & 1) * STAGE);
         __syncthreads();
         issue();
-#if OFX_SCHED & 2
         __builtin_amdgcn_sched_barrier(0);   // keep the loads ahead of the next MFMA block
-#endif
     }
 
     if constexpr (KS == 2) {

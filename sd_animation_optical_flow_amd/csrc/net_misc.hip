@@ -51,7 +51,7 @@ __global__ __launch_bounds__(256) void inorm_partial_kernel(const float* __restr
         red[threadIdx.x * 8 + 4 + k] = q[k];
     }
     __syncthreads();
-    if (threadIdx.x < cg) {
+    if ((int)threadIdx.x < cg) {
         double ts[4] = {0, 0, 0, 0}, tq[4] = {0, 0, 0, 0};
         for (int r = 0; r < rows; ++r)
             for (int k = 0; k < 4; ++k) {
