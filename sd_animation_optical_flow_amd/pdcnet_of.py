@@ -66,11 +66,30 @@ class PDCNetPlus:
         by the batch).  Returns (flow f32[B,H,W,2] on the target grid pointing into source, confidence
         f32[B,H,W], log_confidence f32[B,H,W]) -- all on the device."""
         net = self.network
-        flow_t = net.forward(target, source, iters=self.iters, bgr=bgr)          # target -> source
         if not want_confidence:
-            return flow_t, None, None
-        flow_s = net.forward(source, target, iters=self.iters, bgr=bgr)          # source -> target
-        conf, logc = ops.fb_confidence(flow_t, flow_s, self.sigma)
+            return net.forward(target, source, iters=self.iters, bgr=bgr), None, None          # target -> source
+        # Both directions in ONE indexed-pairs call: every image is encoded once (two separate forwards encode each
+        # image twice) and the forward / backward refinements share their launches (2B pairs per batch).
+        shared = source.dim() == 3
+        src = net.pad_to_8((source[None] if shared else source).contiguous())
+        tgt = net.pad_to_8((target[None] if target.dim() == 3 else target).contiguous())
+        B, ns = tgt.shape[0], src.shape[0]
+        if not shared and ns != B:
+            raise RuntimeError("source / target batch sizes differ")
+        step = max(1, net.max_pairs(tgt.shape[1], tgt.shape[2]) // 2)
+        fts, fss = [], []
+        for b0 in range(0, B, step):
+            t = tgt[b0:b0 + step]
+            s = src if shared else src[b0:b0 + step]
+            n, m = t.shape[0], s.shape[0]
+            it = [m + i for i in range(n)]                     # image index of target i in cat([s, t])
+            isrc = [0] * n if shared else list(range(n))
+            out = net.forward_pairs(torch.cat([s, t]), it + isrc, isrc + it, iters=self.iters, bgr=bgr)
+            fts.append(out[:n])                                # on the target grid, pointing into the source
+            fss.append(out[n:])                                # on the source grid, pointing into the target
+        flow_t = fts[0] if len(fts) == 1 else torch.cat(fts)
+        flow_s = fss[0] if len(fss) == 1 else torch.cat(fss)
+        conf, logc = ops.fb_confidence(flow_t.contiguous(), flow_s.contiguous(), self.sigma)
         return flow_t, conf, logc
 
     @torch.no_grad()

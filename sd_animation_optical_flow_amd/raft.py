@@ -76,6 +76,13 @@ class RaftEngine:
         return self._ws
 
     @staticmethod
+    def max_pairs(H: int, W: int) -> int:
+        """Pairs one executor call can take at this frame size: the convolution kernels address their operands with
+        32-bit byte offsets (buffer descriptors), so the widest array (the 768-float row of the hoisted GRU context
+        term) must stay below 2 GiB.  Larger batches are processed in slices (pairs are independent)."""
+        return max(1, ((1 << 31) - 4096) // (((H + 7) // 8) * ((W + 7) // 8) * 768 * 4))
+
+    @staticmethod
     def pad_to_8(img: torch.Tensor) -> torch.Tensor:
         """InputPadder('sintel') of RAFT/core/utils/utils.py:7-19 for uint8 [B,H,W,3] tensors:
         replicate padding, centred.  No-op when H and W are multiples of 8."""
@@ -119,10 +126,7 @@ class RaftEngine:
             flags |= FLAG_SHARED_IMG2
         if alternate_corr:
             flags |= FLAG_ALT_CORR
-        # the conv kernels address their operands with 32-bit byte offsets (buffer descriptors): the widest
-        # array (the 768-float row of the hoisted GRU context term) must stay below 2 GiB -> larger batches
-        # are processed in slices (pairs are independent)
-        max_pairs = max(1, ((1 << 31) - 4096) // ((H // 8) * (W // 8) * 768 * 4))
+        max_pairs = self.max_pairs(H, W)
         if B > max_pairs:
             ups, lows = [], []
             for b0 in range(0, B, max_pairs):
