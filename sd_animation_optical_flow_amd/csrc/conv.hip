@@ -147,7 +147,18 @@ __global__ __launch_bounds__(256 * KS, (BK == 16 && KS == 1) ? 3 : 1) void igemm
 
     // ---- per-thread gather coordinates for the A (im2col) tile
     const int kq = tid % QPR;   // float4 slot inside the BK-wide k chunk
-    const int r0 = tid / QPR;   // row inside each RPG-row group
+    // row inside each RPG-row group.  fp32 staging: the 16 lanes that one ds_write_b128 pass serves must hit 16
+    // distinct 16-byte bank groups.  With rows LDK floats apart, consecutive rows collide (row 3 of a 4-row group
+    // wraps onto row 0: a third of all LDS cycles were bank conflicts, SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE),
+    // rows S apart with (LDK/4)*S = QPR (mod 16) do not: S = 4 for BK 16, 8 for BK 32.  The permutation only
+    // changes which thread stages which row.
+    constexpr int kG = 16 / QPR, kS = BK == 16 ? 4 : 8;
+    const int j0 = tid / QPR;
+    // bf16 staging (8-byte writes, 32 lanes per pass, rows ROWB = 2*BK + 16 bytes apart): the rows of one pass
+    // must start 32 bytes apart modulo 256 -- same-parity rows for BK 16 (48-byte rows), every 4th row for BK 32
+    const int r0 = PREC == 0 ? (j0 % kG) * kS + (j0 / kG) % kS + (j0 / (kG * kS)) * (kG * kS)
+                   : BK == 16 ? 16 * (j0 / 16) + 2 * (j0 % 8) + ((j0 / 8) & 1)
+                              : 16 * (j0 / 16) + 4 * (j0 % 4) + ((j0 / 4) & 3);
     const int HWo = p.Hout * p.Wout;
     int apix[A_PER], a_iy0[A_PER], a_ix0[A_PER], a_b[NORM ? A_PER : 1];
 #pragma unroll
