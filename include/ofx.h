@@ -134,6 +134,20 @@ int ofx_sd_handoff(const uint8_t* image_bgr, const uint8_t* reference_bgr, const
                    const uint8_t* mask_latent, float* image, float* cond_image, float* cond_mask, float* latmask,
                    float* cond_mask_latent, int B, int H, int W, int h, int w, void* stream);
 
+/* ---------------------------------------------------------------- key-frame detector */
+/* edges[b] = cv2.dilate(cv2.Canny(V, low, high), ones(ksize, ksize)) for BGR frames u8[B,H,W,3], with V = max(B,G,R)
+ * (the HSV value channel) and low/high = int((1 -/+ 1/3) * np.median(V)) clipped to [0,255]
+ * (_detect_edges, ofgen_keyframe_inpaint.py:161-192).  ksize odd (estimated_kernel_size, :153-158).
+ * scratch: ofx_detect_edges_scratch_bytes(B,H,W) bytes, 256-byte aligned.  The hysteresis stage iterates to
+ * convergence and SYNCHRONISES the stream once per sweep.  Parity: OpenCV's algorithm restated; unpinned. */
+size_t ofx_detect_edges_scratch_bytes(int B, int H, int W);
+int ofx_detect_edges(const uint8_t* frames_bgr, uint8_t* edges, void* scratch, size_t scratch_bytes, int B, int H,
+                     int W, int ksize, void* stream);
+/* sums[b] = sum_i |a[b*a_bstride + i] - b_[b*b_bstride + i]|, i < n (mean_pixel_distance's numerator, :143-150);
+ * a stride of 0 compares every image with one shared image.  sums: device u64[B]. */
+int ofx_abs_diff_sum_u8(const uint8_t* a, long a_bstride, const uint8_t* b, long b_bstride,
+                        unsigned long long* sums, int B, long n, void* stream);
+
 /* ---------------------------------------------------------------- implicit-GEMM conv */
 #define OFX_ACT_NONE    0
 #define OFX_ACT_RELU    1

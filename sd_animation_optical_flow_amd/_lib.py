@@ -75,6 +75,9 @@ SIGNATURES = {
     "ofx_gaussian_blur_u8": (_i, [_p, _p, _p, _i, _i, _i, _f, _p]),
     "ofx_resize_bicubic_u8": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "ofx_sd_handoff": (_i, [_p] * 9 + [_i] * 5 + [_p]),
+    "ofx_detect_edges_scratch_bytes": (_z, [_i, _i, _i]),
+    "ofx_detect_edges": (_i, [_p, _p, _p, _z, _i, _i, _i, _i, _p]),
+    "ofx_abs_diff_sum_u8": (_i, [_p, _l, _p, _l, _p, _i, _l, _p]),
     "ofx_inorm_stats": (_i, [_p, _i, _p, _p, _p, _i, _l, _i, _f, _p]),
     "ofx_inorm_apply": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _l, _i, _i, _p]),
     "ofx_preprocess_u8": (_i, [_p, _p, _l, _i, _p]),

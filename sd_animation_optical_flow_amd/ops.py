@@ -405,3 +405,34 @@ def sd_handoff(image_bgr: torch.Tensor, reference_bgr: torch.Tensor, image_mask:
     check(_lib.lib().ofx_sd_handoff(_ptr(a), _ptr(r), _ptr(m), _ptr(ml), _ptr(image), _ptr(cond_image), _ptr(cond_mask), _ptr(latmask),
                                     _ptr(cml), B, H, W, h, w, _stream()), "ofx_sd_handoff")
     return image, cond_image, cond_mask, latmask, cml
+
+
+# --------------------------------------------------------------------------------------
+# key-frame detector
+# --------------------------------------------------------------------------------------
+def detect_edges(frames_bgr: torch.Tensor, ksize: int) -> torch.Tensor:
+    """uint8 [B,H,W,3] (cv2 channel order) -> uint8 [B,H,W] dilated Canny edge maps (_detect_edges of the reference)."""
+    f = _chk(frames_bgr, "frames_bgr", torch.uint8)
+    B, H, W, c3 = f.shape
+    if c3 != 3:
+        raise RuntimeError("frames_bgr must be [B,H,W,3]")
+    L = _lib.lib()
+    need = L.ofx_detect_edges_scratch_bytes(B, H, W)
+    scratch = torch.empty((need,), dtype=torch.uint8, device=f.device)
+    out = torch.empty((B, H, W), dtype=torch.uint8, device=f.device)
+    check(L.ofx_detect_edges(_ptr(f), _ptr(out), _ptr(scratch), need, B, H, W, int(ksize), _stream()), "ofx_detect_edges")
+    return out
+
+
+def abs_diff_sum_u8(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    """a: uint8 [B,...]; b: same shape or one image [...] shared by the batch -> int64 [B] sums of |a - b|."""
+    x = _chk(a, "a", torch.uint8)
+    y = _chk(b, "b", torch.uint8)
+    B = x.shape[0]
+    n = x[0].numel()
+    shared = y.dim() == x.dim() - 1
+    if (shared and y.numel() != n) or (not shared and tuple(y.shape) != tuple(x.shape)):
+        raise RuntimeError("abs_diff_sum_u8: shape mismatch")
+    sums = torch.empty((B,), dtype=torch.int64, device=x.device)
+    check(_lib.lib().ofx_abs_diff_sum_u8(_ptr(x), n, _ptr(y), 0 if shared else n, _ptr(sums), B, n, _stream()), "ofx_abs_diff_sum_u8")
+    return sums

@@ -184,3 +184,34 @@ def test_sd_handoff_primitives_match_pillow_vectors():
     m = (rng.random((40, 56)) < 0.4).astype(np.uint8) * 255
     for radius in (1, 3, 4, 6.5):
         assert np.array_equal(HO.gaussian_blur_u8(m, radius), np.array(Image.fromarray(m).filter(ImageFilter.GaussianBlur(radius))))
+
+
+def test_keyframe_oracle_against_independent_implementations():
+    """The key-frame oracle is unpinned (no OpenCV to compare with); its building blocks are at least checked against
+    independent implementations: scipy's correlate / grey_dilation and a plain flood fill."""
+    from scipy import ndimage
+    from oracle import keyframe_oracle as KO
+    rng = np.random.default_rng(3)
+    lum = ndimage.uniform_filter(rng.integers(0, 256, (37, 45)).astype(np.float32), 5).astype(np.uint8)
+    lum[10:25, 8:30] = np.minimum(lum[10:25, 8:30].astype(int) + 90, 255).astype(np.uint8)
+    dx, dy = KO._sobel16(lum)
+    kx = np.array([[-1, 0, 1], [-2, 0, 2], [-1, 0, 1]])
+    assert np.array_equal(dx, ndimage.correlate(lum.astype(np.int32), kx, mode="nearest"))
+    assert np.array_equal(dy, ndimage.correlate(lum.astype(np.int32), kx.T, mode="nearest"))
+    e = (rng.random((30, 41)) < 0.05).astype(np.uint8) * 255
+    for k in (1, 3, 5, 7):
+        assert np.array_equal(KO.dilate_square(e, k), ndimage.grey_dilation(e, size=(k, k), mode="constant", cval=0))
+    low, high = 40, 110
+    mp = KO.canny_map(lum, low, high)
+    keep = mp == 2                                                  # flood fill from the strong pixels through candidates
+    stack = list(zip(*np.nonzero(keep)))
+    while stack:
+        y, x = stack.pop()
+        for yy in range(max(0, y - 1), min(mp.shape[0], y + 2)):
+            for xx in range(max(0, x - 1), min(mp.shape[1], x + 2)):
+                if mp[yy, xx] == 0 and not keep[yy, xx]:
+                    keep[yy, xx] = True
+                    stack.append((yy, xx))
+    assert np.array_equal(KO.canny(lum, low, high) > 0, keep) and 0 < keep.sum() < keep.size // 2
+    assert KO.canny_thresholds(np.array([[10, 20], [30, 41]], np.uint8)) == (16, 33)     # median 25.0 -> int(16.67), int(33.33)
+    assert KO.TG22 == 13573 and KO.estimated_kernel_size(512, 768) == 7 and KO.gaps(30.0) == (10, 300)
