@@ -114,32 +114,46 @@ __global__ __launch_bounds__(256) void inorm_apply_kernel(const float* __restric
     }
 }
 
-// ---- convex upsample: one wavefront per coarse pixel, lane = (i*8 + j) sub-pixel
+// ---- convex upsample: one wavefront per FOUR horizontally adjacent coarse pixels; lane = (pixel p, quad q):
+// sub-pixels (i, j..j+3) with i = q >> 1, j = (q & 1) * 4.  The 9 x 64 mask logits of a pixel are read as 16-byte
+// loads (4x fewer load instructions than a lane per sub-pixel) and the 4 results leave as two 16-byte stores; the
+// two lanes of a row and the four pixels of the wave make 128-byte output runs.
 __global__ __launch_bounds__(256) void upsample_kernel(const float* __restrict__ coords1, const float* __restrict__ mask,
                                                        float* __restrict__ flow_up, int h, int w, long M) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const long m = (long)blockIdx.x * 4 + wave;
-    if (m >= M) return;
+    const int wq = (w + 3) >> 2;                                   // groups of 4 pixels per coarse row
+    const long grp = (long)blockIdx.x * 4 + wave;
+    const long rows = M / w;                                       // B * h
+    if (grp >= rows * wq) return;
+    const long row = grp / wq;                                     // b*h + y
+    const int xg = (int)(grp - row * wq);
+    const int p = lane >> 4, q = lane & 15;
+    const int x = xg * 4 + p;
+    if (x >= w) return;
+    const int y = (int)(row % h);
+    const long b = row / h;
+    const long m = row * w + x;
+    const float* mk = mask + m * 576 + q * 4;
+    float4 lg[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) lg[k] = *reinterpret_cast<const float4*>(mk + k * 64);
+    float4 mx = lg[0];
+#pragma unroll
+    for (int k = 1; k < 9; ++k) {
+        mx.x = fmaxf(mx.x, lg[k].x); mx.y = fmaxf(mx.y, lg[k].y); mx.z = fmaxf(mx.z, lg[k].z); mx.w = fmaxf(mx.w, lg[k].w);
+    }
+    float4 den = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+        // v_exp_f32 path (~2 ulp): 576 exponentials per coarse pixel made the libm version VALU-bound
+        lg[k].x = __expf(lg[k].x - mx.x); lg[k].y = __expf(lg[k].y - mx.y);
+        lg[k].z = __expf(lg[k].z - mx.z); lg[k].w = __expf(lg[k].w - mx.w);
+        den.x += lg[k].x; den.y += lg[k].y; den.z += lg[k].z; den.w += lg[k].w;
+    }
+    const float4 inv = make_float4(__builtin_amdgcn_rcpf(den.x), __builtin_amdgcn_rcpf(den.y), __builtin_amdgcn_rcpf(den.z),
+                                   __builtin_amdgcn_rcpf(den.w));
+    float4 ax = make_float4(0.f, 0.f, 0.f, 0.f), ay = ax;
     const long hw = (long)h * w;
-    const long b = m / hw;
-    const int rem = (int)(m - b * hw);
-    const int y = rem / w, x = rem - y * w;
-    const float* mk = mask + m * 576;
-    float lg[9];
-    float mx = -INFINITY;
-#pragma unroll
-    for (int k = 0; k < 9; ++k) {
-        lg[k] = mk[k * 64 + lane];
-        mx = fmaxf(mx, lg[k]);
-    }
-    float den = 0.f;
-#pragma unroll
-    for (int k = 0; k < 9; ++k) {
-        lg[k] = __expf(lg[k] - mx);   // v_exp_f32 path (~2 ulp): 576 exponentials per coarse pixel made this kernel VALU-bound
-        den += lg[k];
-    }
-    const float inv_den = __builtin_amdgcn_rcpf(den);
-    float ax = 0.f, ay = 0.f;
 #pragma unroll
     for (int k = 0; k < 9; ++k) {
         const int yy = y + k / 3 - 1, xx = x + k % 3 - 1;
@@ -149,14 +163,15 @@ __global__ __launch_bounds__(256) void upsample_kernel(const float* __restrict__
             fx = 8.0f * (c.x - (float)xx);    // 8 * (coords1 - coords0)
             fy = 8.0f * (c.y - (float)yy);
         }
-        const float wgt = lg[k] * inv_den;
-        ax += wgt * fx;
-        ay += wgt * fy;
+        const float4 wgt = make_float4(lg[k].x * inv.x, lg[k].y * inv.y, lg[k].z * inv.z, lg[k].w * inv.w);
+        ax.x += wgt.x * fx; ax.y += wgt.y * fx; ax.z += wgt.z * fx; ax.w += wgt.w * fx;
+        ay.x += wgt.x * fy; ay.y += wgt.y * fy; ay.z += wgt.z * fy; ay.w += wgt.w * fy;
     }
-    const int i = lane >> 3, j = lane & 7;
+    const int i = q >> 1, j = (q & 1) * 4;
     const long W8 = (long)w * 8;
-    float2* o = reinterpret_cast<float2*>(flow_up) + (b * h * 8 + (long)y * 8 + i) * W8 + (long)x * 8 + j;
-    *o = make_float2(ax, ay);
+    float4* o = reinterpret_cast<float4*>(flow_up + 2 * ((b * h * 8 + (long)y * 8 + i) * W8 + (long)x * 8 + j));
+    o[0] = make_float4(ax.x, ay.x, ax.y, ay.y);
+    o[1] = make_float4(ax.z, ay.z, ax.w, ay.w);
 }
 
 // coords1 = pixel grid, flow4 = 0, hx[:, flow_off:flow_off+2] = 0   (RAFT.initialize_flow, raft.py:63-70)
@@ -269,11 +284,12 @@ int ofx_inorm_apply(const float* x, const float* mean, const float* rstd, const 
 
 int ofx_upsample_flow(const float* coords1, const float* mask, float* flow_up, int B, int h, int w, void* stream) {
     OFX_REQUIRE(coords1 && mask && flow_up && B > 0 && h > 0 && w > 0, OFX_EINVAL);
-    OFX_REQUIRE((((uintptr_t)coords1) & 7u) == 0 && (((uintptr_t)flow_up) & 7u) == 0, OFX_EALIGN);
+    OFX_REQUIRE((((uintptr_t)coords1) & 7u) == 0 && ofx_aligned16(flow_up) && ofx_aligned16(mask), OFX_EALIGN);
     const long M = (long)B * h * w;
     hipStream_t s = (hipStream_t)stream;
     OfxProfScope prof("upsample_flow", s);
-    hipLaunchKernelGGL(upsample_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, s, coords1, mask, flow_up, h, w, M);
+    const long groups = (M / w) * ((w + 3) / 4);   // 4 coarse pixels per wavefront, 4 wavefronts per workgroup
+    hipLaunchKernelGGL(upsample_kernel, dim3((unsigned)((groups + 3) / 4)), dim3(256), 0, s, coords1, mask, flow_up, h, w, M);
     return ofx_launch_status();
 }
 
