@@ -339,6 +339,12 @@ def main():
                                ("warp", "warp"), ("mask", "mask")):
                 if label in ks and tkey in tr:
                     ks[label]["traffic"] = tr[tkey]["hbm_bytes_per_launch_corrected"]
+                    # bytes the memory system actually moved (PMC) over the measured launch time: how hard the kernel
+                    # drives HBM, as opposed to `frac` (algorithmic bytes: how much of that traffic was necessary)
+                    if ks[label].get("avg_launch_ms"):
+                        gbs = ks[label]["traffic"] / (ks[label]["avg_launch_ms"] * 1e-3) / 1e9
+                        ks[label]["traffic_gbs"] = round(gbs, 1)
+                        ks[label]["traffic_frac"] = round(gbs / HBM_PEAK_GBS, 4)
         out["kernels"] = ks
         tot = sum(v["ms"] for v in kern.values())
         out["kernel_time_share"] = {k: round(v["ms"] / tot, 4) for k, v in sorted(kern.items(), key=lambda kv: -kv[1]["ms"])[:8]}
