@@ -111,11 +111,15 @@ __global__ __launch_bounds__(256) void mask_bits_kernel(const BitArgs a) {
         }
     }
     __syncthreads();
-    // ---- phase 2: out[row][c] = OR over dy of OR_{|d| <= hw[dy]} row[dy][c + d]
-    if (threadIdx.x < kTH) {
-        const int t = threadIdx.x;
+    // ---- phase 2: out[row][c] = OR over dy of OR_{|d| <= hw[dy]} row[dy][c + d].  All 256 threads take part: thread
+    // (row, part) handles the structuring-element rows dy = -r + part, -r + part + 8, ... and the partial words are
+    // combined with LDS atomics (one 32-thread wave doing all rows serially was half of this kernel's time)
+    if (threadIdx.x < kTH) outbits[threadIdx.x] = 0;
+    __syncthreads();
+    {
+        const int t = threadIdx.x & (kTH - 1), part = threadIdx.x >> 5;
         unsigned long long acc = 0;
-        for (int dy = -r; dy <= r; ++dy) {
+        for (int dy = -r + part; dy <= r; dy += 256 / kTH) {
             const int hw = a.hw[dy + r];
             if (hw < 0) continue;
             U128 v;
@@ -129,13 +133,83 @@ __global__ __launch_bounds__(256) void mask_bits_kernel(const BitArgs a) {
             }
             acc |= shr(s, r - hw).lo;   // column c <-> bit c + r; dilated value = s[c + r - hw]
         }
-        outbits[t] = acc;
+        if (acc) atomicOr(&outbits[t], acc);
     }
     __syncthreads();
     // ---- phase 3: expand to bytes, 8 pixels per thread
     const int row = threadIdx.x >> 3, seg = threadIdx.x & 7;
     const int y = y0 + row;
     if (y >= a.H) return;
+    const int xs = x0 + seg * 8;
+    if (xs >= a.W) return;
+    const unsigned bits = (unsigned)((outbits[row] >> (seg * 8)) & 0xFFu);
+    const long base = (b * a.H + y) * (long)a.W + xs;
+    if (xs + 8 <= a.W && ((base & 7) == 0)) {
+        unsigned long long v = 0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            if ((bits >> i) & 1u) v |= 0xFFull << (8 * i);
+        if (a.or_mask) v |= *reinterpret_cast<const unsigned long long*>(a.or_mask + base);
+        *reinterpret_cast<unsigned long long*>(a.out + base) = v;
+    } else {
+        for (int i = 0; i < 8 && xs + i < a.W; ++i) {
+            uint8_t v = ((bits >> i) & 1u) ? 255 : 0;
+            if (a.or_mask) v |= a.or_mask[base + i];
+            a.out[base + i] = v;
+        }
+    }
+}
+
+// ---- narrow variant (r <= 4: the 7x7 and 9x9 structuring elements): the tile is 56 output columns wide so that
+// tile + halo is exactly one 64-lane load / one ballot per row, and the dilation runs on 64-bit rows.
+constexpr int kNW = 56, kNH = 4;      // output columns per tile, fixed halo (>= r)
+template <int SRC>
+__global__ __launch_bounds__(256) void mask_bits_narrow_kernel(const BitArgs a) {
+    __shared__ unsigned long long rows[kTH + 2 * kNH];
+    __shared__ unsigned long long outbits[kTH];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = a.r;
+    const int x0 = blockIdx.x * kNW, y0 = blockIdx.y * kTH;
+    const long b = blockIdx.z;
+    const int nrows = kTH + 2 * r;
+    constexpr int kIter = (kTH + 2 * kNH + 3) / 4;
+    bool pa[kIter];
+    const int xa = x0 - kNH + lane;                       // bit p of a row <-> column x0 - kNH + p
+#pragma unroll
+    for (int it = 0; it < kIter; ++it) {
+        const int ry = wave + 4 * it;
+        pa[it] = ry < nrows ? src_bit<SRC>(a, b, y0 - r + ry, xa) : false;
+    }
+#pragma unroll
+    for (int it = 0; it < kIter; ++it) {
+        const int ry = wave + 4 * it;
+        if (ry >= nrows) break;
+        const unsigned long long ma = __ballot(pa[it]);
+        if (lane == 0) rows[ry] = ma;
+        if ((SRC == OFX_MSRC_CONF_LT || SRC == OFX_MSRC_CONF_NGT) && a.log_conf != nullptr && ry >= r && ry < r + kTH) {
+            // generate_mask's side effect: log_confidence[low] = 0 on the tile's own pixels
+            if (pa[it] && lane >= kNH && lane < kNH + kNW && xa < a.W) a.log_conf[(b * a.H + (y0 - r + ry)) * (long)a.W + xa] = 0.f;
+        }
+    }
+    if (threadIdx.x < kTH) outbits[threadIdx.x] = 0;
+    __syncthreads();
+    {
+        const int t = threadIdx.x & (kTH - 1), part = threadIdx.x >> 5;
+        unsigned long long acc = 0;
+        for (int dy = -r + part; dy <= r; dy += 256 / kTH) {
+            const int hw = a.hw[dy + r];
+            if (hw < 0) continue;
+            const unsigned long long v = rows[t + r + dy];
+            unsigned long long s = v;                     // s[q] = OR_{e=0..2hw} v[q+e]
+            for (int e = 1; e <= 2 * hw; ++e) s |= v >> e;
+            acc |= s >> (kNH - hw);                       // column c <-> bit c + kNH; dilated value = s[c + kNH - hw]
+        }
+        if (acc) atomicOr(&outbits[t], acc);
+    }
+    __syncthreads();
+    const int row = threadIdx.x >> 3, seg = threadIdx.x & 7;
+    const int y = y0 + row;
+    if (seg >= kNW / 8 || y >= a.H) return;
     const int xs = x0 + seg * 8;
     if (xs >= a.W) return;
     const unsigned bits = (unsigned)((outbits[row] >> (seg * 8)) & 0xFFu);
@@ -167,8 +241,18 @@ int ofx_mask_bits_launch(int src, const float* conf, float* log_conf, const uint
     a.conf = conf; a.log_conf = log_conf; a.image = image; a.or_mask = or_mask; a.out = out;
     a.H = H; a.W = W; a.thres = thres; a.edge_thres = edge_thres; a.r = r;
     for (int i = 0; i < 2 * kMaxR + 1; ++i) a.hw[i] = i < 2 * r + 1 ? hw[i] : (signed char)-1;
-    dim3 grid(ofx_cdiv(W, kTW), ofx_cdiv(H, kTH), B);
     OfxProfScope prof(name, s);
+    if (r <= kNH) {
+        dim3 gridn(ofx_cdiv(W, kNW), ofx_cdiv(H, kTH), B);
+        switch (src) {
+            case OFX_MSRC_CONF_LT: hipLaunchKernelGGL((mask_bits_narrow_kernel<OFX_MSRC_CONF_LT>), gridn, dim3(256), 0, s, a); break;
+            case OFX_MSRC_CONF_NGT: hipLaunchKernelGGL((mask_bits_narrow_kernel<OFX_MSRC_CONF_NGT>), gridn, dim3(256), 0, s, a); break;
+            case OFX_MSRC_EDGES: hipLaunchKernelGGL((mask_bits_narrow_kernel<OFX_MSRC_EDGES>), gridn, dim3(256), 0, s, a); break;
+            default: return OFX_EINVAL;
+        }
+        return ofx_launch_status();
+    }
+    dim3 grid(ofx_cdiv(W, kTW), ofx_cdiv(H, kTH), B);
     switch (src) {
         case OFX_MSRC_CONF_LT: hipLaunchKernelGGL((mask_bits_kernel<OFX_MSRC_CONF_LT>), grid, dim3(256), 0, s, a); break;
         case OFX_MSRC_CONF_NGT: hipLaunchKernelGGL((mask_bits_kernel<OFX_MSRC_CONF_NGT>), grid, dim3(256), 0, s, a); break;
