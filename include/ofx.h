@@ -224,6 +224,14 @@ int ofx_corr_lookup(const float* const* pyr, const float* coords, float* out, in
  * corr [B,N,(2r+1)^2,H1,W1] (overwritten, not accumulated into).  C % 4 == 0. */
 int ofx_local_corr_fwd(const float* fmap1, const float* fmap2, const float* coords, float* corr,
                        int B, int H1, int W1, int H2, int W2, int C, int N, int r, void* stream);
+/* alt_cuda_corr.backward (correlation_kernel.cu:122-256,288-324): gradients of ofx_local_corr_fwd with respect to
+ * the two feature maps for corr_grad f32[B,N,(2r+1)^2,H1,W1]; fmap1_grad f32[B,H1,W1,C] and fmap2_grad
+ * f32[B,H2,W2,C] are overwritten (the reference returns fresh zero-initialised tensors; its third output,
+ * coords_grad, is all zeros and is left to the caller).  fmap2_grad is accumulated with float atomics like the
+ * reference's atomicAdd, so its low-order bits depend on scheduling.  Training-only in the reference. */
+int ofx_local_corr_bwd(const float* fmap1, const float* fmap2, const float* coords, const float* corr_grad,
+                       float* fmap1_grad, float* fmap2_grad, int B, int H1, int W1, int H2, int W2, int C, int N,
+                       int r, void* stream);
 /* 2x2 average pool of an NHWC tensor (AlternateCorrBlock pyramid, corr.py:68-72) */
 int ofx_avgpool2_nhwc(const float* in, float* out, int B, int H, int W, int C, void* stream);
 

@@ -434,3 +434,46 @@ def raft2_calc(sd, img1_bgr, img2_bgr, iters: int = 20):
     c, _ = pad_to_8(c)
     _, up = raft_forward(sd, a, c, iters=iters)
     return up[0].permute(1, 2, 0).contiguous().numpy()
+
+
+def local_corr_backward(fmap1: Tensor, fmap2: Tensor, coords: Tensor, corr_grad: Tensor, radius: int):
+    """Semantics of `alt_cuda_corr.backward` (correlation_kernel.cu:122-256, :288-324): for every pixel, n and
+    integer tap (iy, ix) the adjoint of the bilinear splat gives one weight g (cu:207-222); then
+    fmap1_grad[pixel] += g * fmap2[tap] and fmap2_grad[tap] += g * fmap1[pixel] (cu:224-237); out-of-range taps
+    contribute nothing; coords_grad is returned as zeros (cu:305).  Returns (fmap1_grad, fmap2_grad, coords_grad)."""
+    b, h1, w1, c = fmap1.shape
+    _, h2, w2, _ = fmap2.shape
+    nn = coords.shape[1]
+    rd = 2 * radius + 1
+    g1 = torch.zeros_like(fmap1)
+    g2 = torch.zeros_like(fmap2)
+    bi = torch.arange(b).reshape(b, 1, 1).expand(b, h1, w1)
+    for n in range(nn):
+        x = coords[:, n, :, :, 0]
+        y = coords[:, n, :, :, 1]
+        x0 = torch.floor(x)
+        y0 = torch.floor(y)
+        dx = x - x0
+        dy = y - y0
+        x0 = x0.long()
+        y0 = y0.long()
+        go = corr_grad[:, n].reshape(b, rd, rd, h1, w1)          # [b, ix, iy, h, w]: channel = iy + rd*ix
+        for iy in range(rd + 1):
+            for ix in range(rd + 1):
+                g = torch.zeros((b, h1, w1), dtype=fmap1.dtype)
+                if iy > 0 and ix > 0:
+                    g = g + go[:, ix - 1, iy - 1] * dy * dx
+                if iy > 0 and ix < rd:
+                    g = g + go[:, ix, iy - 1] * dy * (1 - dx)
+                if iy < rd and ix > 0:
+                    g = g + go[:, ix - 1, iy] * (1 - dy) * dx
+                if iy < rd and ix < rd:
+                    g = g + go[:, ix, iy] * (1 - dy) * (1 - dx)
+                yy = y0 - radius + iy
+                xx = x0 - radius + ix
+                ok = (yy >= 0) & (yy < h2) & (xx >= 0) & (xx < w2)
+                g = torch.where(ok, g, torch.zeros_like(g))
+                yc, xc = yy.clamp(0, h2 - 1), xx.clamp(0, w2 - 1)
+                g1 += g[..., None] * fmap2[bi, yc, xc]
+                g2.index_put_((bi, yc, xc), g[..., None] * fmap1, accumulate=True)
+    return g1, g2, torch.zeros_like(coords)

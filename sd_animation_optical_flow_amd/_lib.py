@@ -84,6 +84,7 @@ SIGNATURES = {
     "ofx_corr_volume": (_i, [_p, _p, C.POINTER(_p), _i, _i, _i, _i, _i, _p]),
     "ofx_corr_lookup": (_i, [C.POINTER(_p), _p, _p, _i, _i, _i, _i, _i, _i, _p]),
     "ofx_local_corr_fwd": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
+    "ofx_local_corr_bwd": (_i, [_p] * 6 + [_i] * 8 + [_p]),
     "ofx_avgpool2_nhwc": (_i, [_p, _p, _i, _i, _i, _i, _p]),
     "ofx_upsample_flow": (_i, [_p, _p, _p, _i, _i, _i, _p]),
     "ofx_raft_create": (_i, [C.POINTER(Tensor), _i, C.POINTER(_p)]),

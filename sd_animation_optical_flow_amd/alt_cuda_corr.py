@@ -7,8 +7,9 @@
 with `corr f32[B,N,(2r+1)^2,H1,W1]`; all tensors must be CUDA and contiguous (RuntimeError otherwise,
 correlation.cpp:19-21).  Unlike the reference, the launch goes to the *current* torch stream (the CUDA
 original uses the legacy default stream) and C only needs to be a multiple of 4 (the original silently
-requires a multiple of 32).  `backward` is training-only (never reached by the reference's no_grad
-callers) and is not provided.
+requires a multiple of 32).  `backward(fmap1, fmap2, coords, corr_grad, radius) -> [fmap1_grad, fmap2_grad,
+coords_grad]` (correlation.cpp:35-49) is provided for completeness of the native inventory; the reference's
+inference callers run under no_grad and never reach it.
 """
 from __future__ import annotations
 
@@ -23,5 +24,6 @@ def forward(fmap1: torch.Tensor, fmap2: torch.Tensor, coords: torch.Tensor, radi
     return [ops.local_corr(fmap1, fmap2, coords, int(radius))]
 
 
-def backward(*args, **kwargs):
-    raise NotImplementedError("alt_cuda_corr.backward is training-only; the inference hot path never calls it")
+def backward(fmap1: torch.Tensor, fmap2: torch.Tensor, coords: torch.Tensor, corr_grad: torch.Tensor, radius: int) -> List[torch.Tensor]:
+    g1, g2 = ops.local_corr_backward(fmap1, fmap2, coords, corr_grad, int(radius))
+    return [g1, g2, torch.zeros_like(coords)]                 # coords_grad is all zeros in the reference too (cu:305)

@@ -296,6 +296,82 @@ __global__ __launch_bounds__(256) void local_corr_kernel(const LocalArgs a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// local correlation, backward (alt_cuda_corr.backward, correlation_kernel.cu:122-256,288-324)
+// ------------------------------------------------------------------------------------------
+// One wavefront per (b, n, pixel): the adjoint of the bilinear splat turns the (2r+1)^2 output gradients into one
+// weight g per integer tap (kept in LDS); then fmap1_grad[pixel] += sum_taps g * f2[tap] stays in registers
+// (a lane owns C/64 channel quads; the wavefront owns the pixel row for n = 0..N-1 in sequence) and
+// fmap2_grad[tap] += g * f1[pixel] goes out through float atomics, like the reference's atomicAdd.
+struct LocalBwdArgs {
+    const float* f1;      // [B,H1,W1,C]
+    const float* f2;      // [B,H2,W2,C]
+    const float* coords;  // [B,N,H1,W1,2]
+    const float* gout;    // [B,N,(2r+1)^2,H1,W1]
+    float* g1;            // [B,H1,W1,C]  (zero-initialised by the launcher)
+    float* g2;            // [B,H2,W2,C]
+    int B, H1, W1, H2, W2, C, N, r;
+    long total;           // B*H1*W1
+};
+
+__global__ __launch_bounds__(256) void local_corr_bwd_kernel(const LocalBwdArgs a) {
+    __shared__ float gw[4][kMaxWin * kMaxWin];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long gp = (long)blockIdx.x * 4 + wave;          // b*H1*W1 + pixel
+    if (gp >= a.total) return;                             // no block-wide barriers below
+    const int rd = 2 * a.r + 1, wn = rd + 1;
+    const long hw1 = (long)a.H1 * a.W1;
+    const long b = gp / hw1;
+    const int pix = (int)(gp - b * hw1);
+    const float* f1 = a.f1 + gp * (long)a.C;
+    const float* f2b = a.f2 + b * (long)a.H2 * a.W2 * a.C;
+    float* g2b = a.g2 + b * (long)a.H2 * a.W2 * a.C;
+    float* g = gw[wave];
+    for (int n = 0; n < a.N; ++n) {
+        const float2 cc = reinterpret_cast<const float2*>(a.coords)[(b * a.N + n) * hw1 + pix];
+        const bool sane = fabsf(cc.x) < 1.0e7f && fabsf(cc.y) < 1.0e7f;
+        const int x0 = sane ? (int)floorf(cc.x) : -100000, y0 = sane ? (int)floorf(cc.y) : -100000;
+        const float dx = sane ? cc.x - floorf(cc.x) : 0.f, dy = sane ? cc.y - floorf(cc.y) : 0.f;
+        const float* go = a.gout + ((b * a.N + n) * (long)rd * rd) * hw1 + pix;
+        // g[iy][ix]: the four splat targets of tap (iy, ix), cu:207-222 (channel = y + rd * x); all 64 lanes take part
+        for (int t = lane; t < wn * wn; t += 64) {
+            const int iy = t / wn, ix = t - iy * wn;
+            float v = 0.f;
+            if (iy > 0 && ix > 0) v += go[(long)((iy - 1) + rd * (ix - 1)) * hw1] * dy * dx;
+            if (iy > 0 && ix < rd) v += go[(long)((iy - 1) + rd * ix) * hw1] * dy * (1.f - dx);
+            if (iy < rd && ix > 0) v += go[(long)(iy + rd * (ix - 1)) * hw1] * (1.f - dy) * dx;
+            if (iy < rd && ix < rd) v += go[(long)(iy + rd * ix) * hw1] * (1.f - dy) * (1.f - dx);
+            g[t] = v;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        for (int c0 = lane * 4; c0 < a.C; c0 += 256) {     // channel quads owned by this lane
+            const float4 u = *reinterpret_cast<const float4*>(f1 + c0);
+            float4 acc1 = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int t = 0; t < wn * wn; ++t) {
+                const int iy = t / wn, ix = t - iy * wn;
+                const int yy = y0 - a.r + iy, xx = x0 - a.r + ix;
+                if ((unsigned)yy >= (unsigned)a.H2 || (unsigned)xx >= (unsigned)a.W2) continue;   // wave-uniform
+                const float gt = g[t];
+                const long off = ((long)yy * a.W2 + xx) * a.C + c0;
+                const float4 v = *reinterpret_cast<const float4*>(f2b + off);
+                acc1.x = fmaf(gt, v.x, acc1.x); acc1.y = fmaf(gt, v.y, acc1.y);
+                acc1.z = fmaf(gt, v.z, acc1.z); acc1.w = fmaf(gt, v.w, acc1.w);
+                atomicAdd(g2b + off + 0, gt * u.x);
+                atomicAdd(g2b + off + 1, gt * u.y);
+                atomicAdd(g2b + off + 2, gt * u.z);
+                atomicAdd(g2b + off + 3, gt * u.w);
+            }
+            // this wavefront is the only writer of its pixel's fmap1_grad row (zeroed by the launcher)
+            float4* o = reinterpret_cast<float4*>(a.g1 + gp * (long)a.C + c0);
+            const float4 prev = *o;
+            *o = make_float4(prev.x + acc1.x, prev.y + acc1.y, prev.z + acc1.z, prev.w + acc1.w);
+        }
+        __builtin_amdgcn_wave_barrier();                   // g[] is rewritten by the next n
+    }
+}
+
 __global__ __launch_bounds__(256) void avgpool2_nhwc_kernel(const float* __restrict__ in, float* __restrict__ out,
                                                             int H, int W, int C, long total4) {
     const int Ho = H / 2, Wo = W / 2, C4 = C / 4;
@@ -410,6 +486,26 @@ int ofx_local_corr_fwd(const float* fmap1, const float* fmap2, const float* coor
     const long hw = (long)H1 * W1;
     return ofx_local_corr_launch(fmap1, fmap2, coords, corr, (long)N * rd2 * hw, rd2 * hw, hw, 1, B, H1, W1, H2, W2, C,
                                  N, r, 1.0f, 1.0f, (hipStream_t)stream);
+}
+
+int ofx_local_corr_bwd(const float* fmap1, const float* fmap2, const float* coords, const float* corr_grad, float* fmap1_grad,
+                       float* fmap2_grad, int B, int H1, int W1, int H2, int W2, int C, int N, int r, void* stream) {
+    OFX_REQUIRE(fmap1 && fmap2 && coords && corr_grad && fmap1_grad && fmap2_grad, OFX_EINVAL);
+    OFX_REQUIRE(B > 0 && H1 > 0 && W1 > 0 && H2 > 0 && W2 > 0 && C > 0 && N > 0, OFX_EINVAL);
+    OFX_REQUIRE(r >= 0 && 2 * r + 2 <= kMaxWin, OFX_EINVAL);
+    OFX_REQUIRE(C % 4 == 0 && ofx_aligned16(fmap1) && ofx_aligned16(fmap2) && ofx_aligned16(fmap1_grad) && ofx_aligned16(fmap2_grad),
+                OFX_EALIGN);
+    hipStream_t s = (hipStream_t)stream;
+    LocalBwdArgs a;
+    a.f1 = fmap1; a.f2 = fmap2; a.coords = coords; a.gout = corr_grad; a.g1 = fmap1_grad; a.g2 = fmap2_grad;
+    a.B = B; a.H1 = H1; a.W1 = W1; a.H2 = H2; a.W2 = W2; a.C = C; a.N = N; a.r = r;
+    a.total = (long)B * H1 * W1;
+    // fresh zeros like the reference's torch::zeros (cu:303-305)
+    OFX_HIP_CHECK(hipMemsetAsync(fmap1_grad, 0, (size_t)B * H1 * W1 * C * sizeof(float), s));
+    OFX_HIP_CHECK(hipMemsetAsync(fmap2_grad, 0, (size_t)B * H2 * W2 * C * sizeof(float), s));
+    OfxProfScope prof("local_corr_bwd", s);
+    hipLaunchKernelGGL(local_corr_bwd_kernel, dim3((unsigned)((a.total + 3) / 4)), dim3(256), 0, s, a);
+    return ofx_launch_status();
 }
 
 int ofx_avgpool2_nhwc(const float* in, float* out, int B, int H, int W, int C, void* stream) {

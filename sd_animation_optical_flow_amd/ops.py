@@ -344,6 +344,25 @@ def local_corr(fmap1: torch.Tensor, fmap2: torch.Tensor, coords: torch.Tensor, r
     return out
 
 
+def local_corr_backward(fmap1: torch.Tensor, fmap2: torch.Tensor, coords: torch.Tensor, corr_grad: torch.Tensor, radius: int):
+    """`alt_cuda_corr.backward` semantics: (fmap1_grad, fmap2_grad) for corr_grad f32[B,N,(2r+1)^2,H1,W1]."""
+    a = _chk(fmap1, "fmap1", torch.float32)
+    b = _chk(fmap2, "fmap2", torch.float32)
+    c = _chk(coords, "coords", torch.float32)
+    g = _chk(corr_grad, "corr_grad", torch.float32)
+    B, H1, W1, Cn = a.shape
+    _, H2, W2, _ = b.shape
+    N = c.shape[1]
+    rd = 2 * radius + 1
+    if tuple(g.shape) != (B, N, rd * rd, H1, W1):
+        raise RuntimeError(f"corr_grad must be {(B, N, rd * rd, H1, W1)}, got {tuple(g.shape)}")
+    g1 = torch.empty_like(a)
+    g2 = torch.empty_like(b)
+    check(_lib.lib().ofx_local_corr_bwd(_ptr(a), _ptr(b), _ptr(c), _ptr(g), _ptr(g1), _ptr(g2), B, H1, W1, H2, W2, Cn, N, radius,
+                                        _stream()), "ofx_local_corr_bwd")
+    return g1, g2
+
+
 def avgpool2_nhwc(x: torch.Tensor) -> torch.Tensor:
     x = _chk(x, "x", torch.float32)
     B, H, W, Cn = x.shape

@@ -195,6 +195,27 @@ def test_corr_volume_pyramid_and_lookup(cuda, shape):
         assert err < 1e-4, (amp, err)
 
 
+def test_local_corr_backward_matches_oracle(cuda):
+    """alt_cuda_corr.backward: gradients w.r.t. both feature maps against the oracle's restatement (itself equal to
+    autograd of the pinned forward); C below, equal to and above one lane-quad sweep (64, 256, 320)."""
+    from sd_animation_optical_flow_amd import alt_cuda_corr
+    g = torch.Generator().manual_seed(16)
+    for (B, h, w, h2, w2, C, N, r) in ((2, 9, 11, 5, 6, 64, 2, 3), (1, 6, 5, 6, 5, 256, 1, 4), (1, 4, 6, 3, 4, 320, 2, 1)):
+        f1 = torch.randn((B, h, w, C), generator=g)
+        f2 = torch.randn((B, h2, w2, C), generator=g)
+        base = torch.stack(torch.meshgrid(torch.arange(w).float(), torch.arange(h).float(), indexing="xy"), -1)
+        coords = (base[None, None] * (w2 / w) + (torch.rand((B, N, h, w, 2), generator=g) - 0.5) * 7).contiguous()
+        gout = torch.randn((B, N, (2 * r + 1) ** 2, h, w), generator=g)
+        r1, r2, _ = RO.local_corr_backward(f1, f2, coords, gout, r)
+        o1, o2, oc = alt_cuda_corr.backward(f1.cuda(), f2.cuda(), coords.cuda(), gout.cuda(), r)
+        s1, s2 = max(1.0, r1.abs().max().item()), max(1.0, r2.abs().max().item())
+        assert (o1.cpu() - r1).abs().max().item() < 2e-5 * s1, (C, (o1.cpu() - r1).abs().max().item())
+        assert (o2.cpu() - r2).abs().max().item() < 2e-5 * s2, (C, (o2.cpu() - r2).abs().max().item())
+        assert tuple(oc.shape) == tuple(coords.shape) and float(oc.abs().max()) == 0.0
+    with pytest.raises(RuntimeError):
+        alt_cuda_corr.backward(f1.cuda(), f2.cuda(), coords.cuda(), gout.cuda()[:, :, :1], r)      # wrong corr_grad shape
+
+
 def test_local_corr_matches_alt_cuda_corr_semantics(cuda):
     ops = _ops()
     g = torch.Generator().manual_seed(6)

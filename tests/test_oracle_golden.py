@@ -215,3 +215,20 @@ def test_keyframe_oracle_against_independent_implementations():
     assert np.array_equal(KO.canny(lum, low, high) > 0, keep) and 0 < keep.sum() < keep.size // 2
     assert KO.canny_thresholds(np.array([[10, 20], [30, 41]], np.uint8)) == (16, 33)     # median 25.0 -> int(16.67), int(33.33)
     assert KO.TG22 == 13573 and KO.estimated_kernel_size(512, 768) == 7 and KO.gaps(30.0) == (10, 300)
+
+
+def test_local_corr_backward_is_the_adjoint_of_the_pinned_forward():
+    """alt_cuda_corr.backward restated (cu:122-256) == autograd of the restated forward, whose values are pinned to
+    the reference's CorrBlock through the golden file (the CUDA source itself cannot be built here)."""
+    g = torch.Generator().manual_seed(12)
+    B, H1, W1, H2, W2, C, N, r = 2, 6, 7, 5, 6, 8, 2, 2
+    f1 = torch.randn((B, H1, W1, C), generator=g, requires_grad=True)
+    f2 = torch.randn((B, H2, W2, C), generator=g, requires_grad=True)
+    base = torch.stack(torch.meshgrid(torch.arange(W1).float(), torch.arange(H1).float(), indexing="xy"), -1)
+    coords = (base[None, None] * 0.8 + (torch.rand((B, N, H1, W1, 2), generator=g) - 0.5) * 6).contiguous()   # some taps leave fmap2
+    out = RO.local_corr_level(f1, f2, coords, r)
+    gout = torch.randn(out.shape, generator=g)
+    a1, a2 = torch.autograd.grad(out, [f1, f2], grad_outputs=gout)
+    g1, g2, gc = RO.local_corr_backward(f1.detach(), f2.detach(), coords, gout, r)
+    assert (g1 - a1).abs().max().item() < 1e-5 and (g2 - a2).abs().max().item() < 1e-5
+    assert gc.shape == coords.shape and float(gc.abs().max()) == 0.0
