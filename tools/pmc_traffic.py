@@ -21,8 +21,8 @@ FAMILIES = [
     ("pyramid_pool", lambda n, gy: "pyramid_pool_kernel" in n),
     ("upsample", lambda n, gy: "upsample_kernel" in n),
     ("flow_head", lambda n, gy: "flow_head_kernel" in n),
-    ("warp", lambda n, gy: "warp_u8c3_x4_kernel" in n or "warp_kernel" in n),
-    ("mask", lambda n, gy: "mask_bits_kernel" in n),
+    ("warp", lambda n, gy: "warp_u8c3_x4_kernel" in n or "warp_kernel" in n or "warp_bilinear_u8c3_kernel" in n),
+    ("mask", lambda n, gy: "mask_bits" in n),
 ]
 
 
