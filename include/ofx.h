@@ -264,7 +264,9 @@ size_t ofx_raft_workspace_bytes(const ofx_raft* r, int B, int H, int W);
                                      independent chains on internal side streams, joined before returning) */
 
 /* RAFT.forward(test_mode=True): image1/image2 u8 [B,H,W,3] on device -> flow_up f32[B,H,W,2]
- * (flow on image1's grid pointing into image2) and, if non-NULL, flow_low f32[B,H/8,W/8,2]. */
+ * (flow on image1's grid pointing into image2) and, if non-NULL, flow_low f32[B,H/8,W/8,2].
+ * One call takes at most (2^31 - 4096) / ((H/8)*(W/8)*3072) pairs (113 at 512x768): the kernels address their
+ * operands with 32-bit byte offsets; OFX_EINVAL beyond that -- pairs are independent, slice the batch. */
 int ofx_raft_forward(ofx_raft* r, const uint8_t* image1, const uint8_t* image2, int B, int H, int W,
                      int iters, int flags, float* flow_up, float* flow_low, void* workspace,
                      size_t workspace_bytes, void* stream);
