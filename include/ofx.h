@@ -188,6 +188,11 @@ typedef struct ofx_conv_desc {
                                                     tiles 128x{32,64,128,192}, 64x64; BK 16 or 32; the 2e9 marker selects the
                                                     paired-pipeline variant of the 64x64 / BK 32 tile (small grids) */
     int precision;                               /* OFX_PREC_FP32 (default, exact fp32 MFMA) or OFX_PREC_BF16X3 */
+    void* splitk_ws;                             /* optional device scratch (256-byte aligned) for split-K on small grids: */
+    size_t splitk_ws_bytes;                      /* partial tiles + per-tile arrival counters.  The first 64 KiB hold the
+                                                    counters and must be ZERO before the first use (the kernel leaves them
+                                                    zero); one scratch per stream that may run a convolution concurrently.
+                                                    NULL / 0: never split. */
 } ofx_conv_desc;
 
 int ofx_conv2d(const ofx_conv_desc* d, void* stream);

@@ -40,6 +40,7 @@ class ConvDesc(C.Structure):
         ("Cout", C.c_int), ("KH", C.c_int), ("KW", C.c_int), ("stride", C.c_int),
         ("padH", C.c_int), ("padW", C.c_int),
         ("act", C.c_int), ("epi", C.c_int), ("tile", C.c_int), ("precision", C.c_int),
+        ("splitk_ws", C.c_void_p), ("splitk_ws_bytes", C.c_size_t),
     ]
 
 

@@ -65,6 +65,9 @@ struct ConvK {
     int K, Kpad, M, act;
     int mtiles, ntiles;
     int group_m;                    // > 1: tiles are ordered M-fastest inside groups of group_m M-tiles (wide-N GEMMs)
+    int ksplit;                     // > 1: split-K over workgroups (small grids); blockIdx.x = tile * ksplit + split
+    float* sk_part;                 // [tile][split][BM*BN] partial accumulators
+    int* sk_count;                  // [tile] arrival counters (zero outside a launch)
     float alpha;
     unsigned magic_cin, magic_kw;   // ceil(2^32/d) for d = cin, KW (0 when d == 1): k/d = umulhi(k, magic)
     unsigned kw1_mask;              // all ones when KW == 1 (then tap / KW = tap), else 0
@@ -79,7 +82,7 @@ constexpr int kKAlign = 32;   // packed weights are zero-padded along K to this 
 // two accumulators are added through LDS before the epilogue.  A grid of one workgroup per CU is bound by the
 // latency of its two chunks in flight -- this doubles the loads in flight and the waves per SIMD without
 // touching the tile shape or the epilogue.
-template <int BM, int BN, int WM, int WN, int EPI, bool NORM, int BK, int PREC, int KS = 1>
+template <int BM, int BN, int WM, int WN, int EPI, bool NORM, int BK, int PREC, int KS = 1, bool SK = false>
 __global__ __launch_bounds__(256 * KS, (BK == 16 && KS == 1) ? 3 : 1) void igemm_kernel(const ConvK p) {
     constexpr int TM = WM / 32, TN = WN / 32;
     constexpr int WAVES_N = BN / WN;
@@ -109,7 +112,9 @@ __global__ __launch_bounds__(256 * KS, (BK == 16 && KS == 1) ? 3 : 1) void igemm
     // XCD-aware bijective remap: hardware places block b on XCD b%8; give each XCD a contiguous
     // range of logical tiles so N-tiles sharing an A tile (and neighbouring M-tiles sharing halo
     // rows) hit the same private L2.
-    const int nblk = p.mtiles * p.ntiles;
+    // split-K: consecutive blocks are the splits of one tile (they land on one XCD through the remap below, so the
+    // partial tiles they exchange stay in that XCD's L2)
+    const int nblk = p.mtiles * p.ntiles * (SK ? p.ksplit : 1);
     const int bid = blockIdx.x;
     const int q8 = nblk >> 3, r8 = nblk & 7;
     const int xcd = bid & 7, idx = bid >> 3;
@@ -119,7 +124,13 @@ __global__ __launch_bounds__(256 * KS, (BK == 16 && KS == 1) ? 3 : 1) void igemm
     // through the 4 MB L2 once per M-tile, so tiles are walked M-fastest inside groups of group_m M-tiles --
     // the workgroups in flight then share a few A tiles and a few B tiles that all stay resident.
     int nt, mt;
-    if (p.group_m <= 1) {
+    int split = 0;
+    if (SK) {
+        split = L % p.ksplit;
+        const int tl = L / p.ksplit;
+        nt = tl % p.ntiles;
+        mt = tl / p.ntiles;
+    } else if (p.group_m <= 1) {
         nt = L % p.ntiles;
         mt = L / p.ntiles;
     } else {
@@ -187,7 +198,12 @@ __global__ __launch_bounds__(256 * KS, (BK == 16 && KS == 1) ? 3 : 1) void igemm
 
     // chunks of this pipeline: grp, grp + KS, ...  (an index past the end addresses k >= K: the A operand
     // reads as zero there, so the surplus iteration of the odd pipeline adds nothing)
-    const int nk = (p.Kpad / BK + KS - 1) / KS;
+    // split-K: this workgroup takes the chunks [kbase, kbase + nk_s) of the K axis
+    const int nk_all = p.Kpad / BK;
+    const int per_split = SK ? (nk_all + p.ksplit - 1) / p.ksplit : nk_all;
+    const int kbase = split * per_split;
+    const int nk_s = max(0, min(per_split, nk_all - kbase));
+    const int nk = (nk_s + KS - 1) / KS;
     const int frag_row = lane & 31;
     const int frag_k = (lane >> 5) * 4;
 
@@ -204,7 +220,7 @@ __global__ __launch_bounds__(256 * KS, (BK == 16 && KS == 1) ? 3 : 1) void igemm
     auto offsets = [&](int chunk) __attribute__((always_inline)) {
         // byte offsets of chunk `chunk`: pure VALU, no memory access -> the scheduler interleaves it
         // with the MFMA block that follows it in the steady-state loop body
-        const int k0 = (chunk * KS + grp) * BK;
+        const int k0 = ((kbase + chunk * KS) + grp) * BK;
         const int k = k0 + kq * 4;
         const int tap = (int)__umulhi((unsigned)k, p.magic_cin);
         const int cch = k - tap * p.cin;
@@ -417,6 +433,53 @@ __global__ __launch_bounds__(256 * KS, (BK == 16 && KS == 1) ? 3 : 1) void igemm
                 for (int e = 0; e < 16; ++e) acc[i][j][e] += smem_all[((i * TN + j) * 16 + e) * 256 + tid];
     }
 
+    if constexpr (SK) {
+        // Serial split-K: every split parks its accumulator tile, the LAST workgroup to arrive (per-tile counter) sums
+        // the S partial tiles in index order (so the result does not depend on who arrived last) and runs the normal
+        // epilogue -- no separate reduction launch.  The partial tiles travel through agent-scope (sc1) stores and
+        // loads, which are coherent across CUs and XCDs without flushing the L2 (an agent-scope release fence writes
+        // the whole L2 back: measured 2x slower end to end).
+        __shared__ int sk_last;
+        const int tile_id = mt * p.ntiles + nt;
+        float* mine = p.sk_part + ((long)tile_id * p.ksplit + split) * (BM * BN);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e)
+                    __hip_atomic_store(mine + ((i * TN + j) * 16 + e) * 256 + tid, acc[i][j][e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");     // this wave's stores have been acknowledged
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const int old = __hip_atomic_fetch_add(p.sk_count + tile_id, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            sk_last = old == p.ksplit - 1;
+            if (sk_last) __hip_atomic_store(p.sk_count + tile_id, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+        }
+        __syncthreads();
+        if (!sk_last) return;
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                f32x16 sum;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) sum[e] = 0.f;
+                for (int s2 = 0; s2 < p.ksplit; ++s2) {
+                    const float* other = p.sk_part + ((long)tile_id * p.ksplit + s2) * (BM * BN);
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const float v = s2 == split ? acc[i][j][e]
+                                                    : __hip_atomic_load(other + ((i * TN + j) * 16 + e) * 256 + tid, __ATOMIC_RELAXED,
+                                                                        __HIP_MEMORY_SCOPE_AGENT);
+                        sum[e] += v;
+                    }
+                }
+                acc[i][j] = sum;
+            }
+    }
+
     // ---- epilogue.  C/D layout of the 32x32 MFMA: col (n) = lane&31, row (m) = (e&3) + 8*(e>>2) + 4*(lane>>5).
     // Each 32x32 sub-tile runs in two phases -- every global read it needs (addend, residual, z, h) is
     // issued first, then the arithmetic and the stores.  The epilogue reads and writes the same buffers (h
@@ -563,24 +626,24 @@ __global__ __launch_bounds__(256 * KS, (BK == 16 && KS == 1) ? 3 : 1) void igemm
     else epilogue(std::false_type{});
 }
 
-template <int BM, int BN, int WM, int WN, int BK, int PREC = 0, int KS = 1>
+template <int BM, int BN, int WM, int WN, int BK, int PREC = 0, int KS = 1, bool SK = false>
 int launch_tile(const ConvK& k, int epi, bool norm, int nz, hipStream_t s) {
-    dim3 grid((unsigned)(k.mtiles * k.ntiles), (unsigned)nz, 1);
+    dim3 grid((unsigned)(k.mtiles * k.ntiles * (k.ksplit > 1 ? k.ksplit : 1)), (unsigned)nz, 1);
     dim3 block(256 * KS, 1, 1);
     switch (epi) {
         case OFX_EPI_PLAIN:
             if (k.act >= OFX_ACT_SIGMOID) {
                 if (norm) return OFX_EINVAL;   // fused-norm producer layers are followed by ReLU / identity only
-                hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, kEpiPlainT, false, BK, PREC, KS>), grid, block, 0, s, k);
+                hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, kEpiPlainT, false, BK, PREC, KS, SK>), grid, block, 0, s, k);
             } else if (norm) {
-                hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, OFX_EPI_PLAIN, true, BK, PREC, KS>), grid, block, 0, s, k);
+                hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, OFX_EPI_PLAIN, true, BK, PREC, KS, SK>), grid, block, 0, s, k);
             } else {
-                hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, OFX_EPI_PLAIN, false, BK, PREC, KS>), grid, block, 0, s, k);
+                hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, OFX_EPI_PLAIN, false, BK, PREC, KS, SK>), grid, block, 0, s, k);
             }
             break;
-        case OFX_EPI_GRU_ZR: hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, OFX_EPI_GRU_ZR, false, BK, PREC, KS>), grid, block, 0, s, k); break;
-        case OFX_EPI_GRU_Q: hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, OFX_EPI_GRU_Q, false, BK, PREC, KS>), grid, block, 0, s, k); break;
-        case OFX_EPI_FLOW: hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, OFX_EPI_FLOW, false, BK, PREC, KS>), grid, block, 0, s, k); break;
+        case OFX_EPI_GRU_ZR: hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, OFX_EPI_GRU_ZR, false, BK, PREC, KS, SK>), grid, block, 0, s, k); break;
+        case OFX_EPI_GRU_Q: hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, OFX_EPI_GRU_Q, false, BK, PREC, KS, SK>), grid, block, 0, s, k); break;
+        case OFX_EPI_FLOW: hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, OFX_EPI_FLOW, false, BK, PREC, KS, SK>), grid, block, 0, s, k); break;
         default: return OFX_EINVAL;
     }
     return ofx_launch_status();
@@ -710,6 +773,31 @@ extern "C" int ofx_conv2d_alpha(const ofx_conv_desc* d, float alpha, void* strea
     k.mtiles = (int)((M + bm - 1) / bm);
     k.ntiles = (d->Cout + bn - 1) / bn;
     k.group_m = k.ntiles >= 8 ? 8 : 1;
+    // split-K (fp32, 64x64 tiles, single z): a grid of a few hundred tiles leaves a 256-CU part with a half-empty
+    // second round (384 tiles = 1.5 per CU: the makespan is 2 tiles); S splits make 384*S shorter work items that
+    // balance.  Needs caller scratch: 64 KiB of counters + tiles * S * 64*64 floats.
+    k.ksplit = 1; k.sk_part = nullptr; k.sk_count = nullptr;
+    if (d->splitk_ws && d->precision == OFX_PREC_FP32 && bm == 64 && bn == 64 && nz == 1 && d->tile == 0) {
+        const long tiles = (long)k.mtiles * k.ntiles;
+        const int nk32 = (int)(k.Kpad / 32);
+        // work per CU in tile units if the tiles are cut S ways: ceil(tiles * S / 256) / S -- take the S that
+        // minimises it (ties: fewer splits), with at least six 32-wide chunks per split
+        int S = 1;
+        if (tiles <= 512 && nk32 >= 12) {
+            double best = (double)((tiles + 255) / 256);
+            for (int c = 2; c <= 4; ++c) {
+                if (nk32 / c < 6) break;
+                const double span = (double)((tiles * c + 255) / 256) / c;
+                if (span < best - 1e-9) { best = span; S = c; }
+            }
+        }
+        const size_t need = 65536 + (size_t)tiles * S * 64 * 64 * sizeof(float);
+        if (S > 1 && tiles * sizeof(int) <= 65536 && need <= d->splitk_ws_bytes && ofx_aligned16(d->splitk_ws)) {
+            k.ksplit = S;
+            k.sk_count = (int*)d->splitk_ws;
+            k.sk_part = (float*)((char*)d->splitk_ws + 65536);
+        }
+    }
     hipStream_t s = (hipStream_t)stream;
     const bool norm = d->nmean != nullptr;
     const char* pname = nz > 1 ? "igemm_corr_volume"
@@ -750,6 +838,7 @@ extern "C" int ofx_conv2d_alpha(const ofx_conv_desc* d, float alpha, void* strea
     if (bm == 64 && bn == 64 && bk == 16) return launch_tile<64, 64, 32, 32, 16>(k, d->epi, norm, nz, s);
     // a grid of at most ~2 workgroups per CU is latency-bound: pair the pipelines (tile + 2e9 forces it, an explicit tile without that forbids it)
     const long blocks = (long)k.mtiles * k.ntiles * nz;
+    if (k.ksplit > 1) return launch_tile<64, 64, 32, 32, 32, 0, 1, true>(k, d->epi, norm, nz, s);
     const bool pair = d->tile >= 2000000000 || (d->tile < 1000000 && blocks <= 640 && k.Kpad >= 8 * 32);
     if (bm == 64 && bn == 64 && pair) return launch_tile<64, 64, 32, 32, 32, 0, 2>(k, d->epi, norm, nz, s);
     if (bm == 64 && bn == 64) return launch_tile<64, 64, 32, 32, 32>(k, d->epi, norm, nz, s);

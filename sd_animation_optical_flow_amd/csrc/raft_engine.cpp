@@ -275,6 +275,8 @@ struct Launcher {
     const float* addend = nullptr;   // consumed (and cleared) by the next conv() call
     int ldadd = 0;
     int precision = OFX_PREC_FP32;   // sticky: OFX_PREC_BF16X3 when the forward was asked for the split-bf16 mode
+    void* sk_ws = nullptr;           // split-K scratch of the stream this launcher feeds (null: never split)
+    size_t sk_bytes = 0;
     // generic conv launch; all pointer plumbing in one place
     void conv(const ConvW& c, const float* in0, int ld0, int c0, const float* in1, int ld1, int c1, float* out, int ldo,
               int B, int Hin, int Win, int stride, int act, int epi = OFX_EPI_PLAIN, const float* res = nullptr,
@@ -304,6 +306,7 @@ struct Launcher {
         d.Cout = cout; d.KH = c.kh; d.KW = c.kw; d.stride = stride; d.padH = padH; d.padW = padW;
         d.act = act; d.epi = epi;
         d.precision = wsplit ? OFX_PREC_BF16X3_W : precision;
+        d.splitk_ws = sk_ws; d.splitk_ws_bytes = sk_bytes;
         if (c0 + c1 != c.cin_pad) { st = OFX_EKEY; return; }
         ofx_prof_set_tag(c.name.c_str());
         st = ofx_conv2d(&d, s);
@@ -330,7 +333,11 @@ struct Streams {
     }
 };
 
+constexpr size_t SK_BYTES = 65536 + (size_t)512 * 4 * 64 * 64 * sizeof(float);   // counters + 512 tiles x 4 splits (conv.hip)
+
 struct EncBufs {
+    void* sk = nullptr;      // split-K scratch of the stream this encoder chain runs on
+    size_t sk_bytes = 0;
     float *x0, *X, *Y, *R1, *R2, *R3;
     float* stats;     // 6 x [chunk][128] floats (mean/rstd for up to 3 norms)
     float* scratch;   // inorm partial sums
@@ -345,6 +352,7 @@ static int run_encoder(ofx_raft* r, const std::string& enc, bool bn, const uint8
     // `out`: [n*h*w][out_ld]; fnet writes 256 channels; cnet writes tanh(0:128) | relu(128:256)
     Launcher L{s};
     L.precision = precision;
+    L.sk_ws = eb.sk; L.sk_bytes = eb.sk_bytes;
     const int H2 = H / 2, W2 = W / 2, H4 = H / 4, W4 = W / 4, H8 = H / 8, W8 = W / 8;
     const int SC = ENC_CHUNK * 128;   // floats per stats vector slot
     float* m1 = eb.stats + 0 * SC; float* s1 = eb.stats + 1 * SC;
@@ -418,6 +426,7 @@ static int run_encoder(ofx_raft* r, const std::string& enc, bool bn, const uint8
 // workspace layout shared by the size query and the forward
 struct RaftWs {
     EncBufs eb[3];    // [1], [2] only exist (else alias [0]) when the encoders may run concurrently
+    void* sk[3];      // split-K scratch per stream (small batches only; null otherwise)
     float *fmap1, *fmap2, *f2l[LEVELS];
     float* ctx;       // indexed-pairs mode: per-image context features [n][N][256] (tanh | relu halves)
     int* idx_dev;     // indexed-pairs mode: image1 index per pair
@@ -436,12 +445,15 @@ static RaftWs carve(void* base, size_t cap, int B, int H, int W, int flags, int 
     const int most = n_images > 0 ? n_images : 2 * B;
     const int nch = std::min(enc_chunk(H, W), most);
     const long half = (long)(H / 2) * (W / 2) * 64;
+    for (int e = 0; e < 3; ++e) w.sk[e] = overlap_pays(M) ? (void*)c.take(SK_BYTES / sizeof(float)) : nullptr;
     for (int e = 0; e < 3; ++e) {
         if (e > 0 && !overlap_pays(M)) {
             w.eb[e] = w.eb[0];
             continue;
         }
         EncBufs& eb = w.eb[e];
+        eb.sk = w.sk[e];
+        eb.sk_bytes = w.sk[e] ? SK_BYTES : 0;
         eb.x0 = c.take((size_t)nch * H * W * 4);
         eb.X = c.take((size_t)nch * half);
         eb.Y = c.take((size_t)nch * half);
@@ -493,6 +505,7 @@ static int run_recurrence(ofx_raft* r, const RaftWs& ws, int B, int h, int w, in
     {   // loop-invariant GRU terms: conv(W[:, inp], inp) + bias for z|r and q of both passes
         Launcher G{s};
         G.precision = precision;
+        G.sk_ws = ws.sk[0]; G.sk_bytes = ws.sk[0] ? SK_BYTES : 0;
         const char* names[4] = {"gru.zr1.inp", "gru.q1.inp", "gru.zr2.inp", "gru.q2.inp"};
         const int offs[4] = {0, 2 * HD, 3 * HD, 5 * HD};
         for (int i = 0; i < 4; ++i)
@@ -503,9 +516,11 @@ static int run_recurrence(ofx_raft* r, const RaftWs& ws, int B, int h, int w, in
 
     Launcher L{s};
     L.precision = precision;
+    L.sk_ws = ws.sk[0]; L.sk_bytes = ws.sk[0] ? SK_BYTES : 0;
     const Streams S{r, s, overlap};
     Launcher LF{S.get(0)};   // flow branch of the motion encoder: independent of the correlation branch
     LF.precision = precision;
+    LF.sk_ws = overlap ? ws.sk[1] : ws.sk[0]; LF.sk_bytes = LF.sk_ws ? SK_BYTES : 0;   // its own scratch when it runs concurrently
     auto C = [&](const char* k) -> const ConvW& { return r->convs[k]; };
     const float* pyr_c[LEVELS] = {ws.pyr[0], ws.pyr[1], ws.pyr[2], ws.pyr[3]};
     const int rd2 = (2 * RADIUS + 1) * (2 * RADIUS + 1);
@@ -639,6 +654,8 @@ int ofx_raft_forward(ofx_raft* r, const uint8_t* image1, const uint8_t* image2, 
     RaftWs ws = carve(workspace, workspace_bytes, B, H, W, flags);
     OFX_REQUIRE(ws.bytes <= workspace_bytes, OFX_ENOMEM);
     hipStream_t s = (hipStream_t)stream;
+    for (int e = 0; e < 3; ++e)   // split-K arrival counters start at zero (the kernels leave them at zero)
+        if (ws.sk[e]) OFX_HIP_CHECK(hipMemsetAsync(ws.sk[e], 0, 65536, s));
     const int h = H / 8, w = W / 8;
     const long N = (long)h * w;
     const long M = (long)B * N;
@@ -744,6 +761,8 @@ int ofx_raft_forward_pairs(ofx_raft* r, const uint8_t* images, int n_images, con
     RaftWs ws = carve(workspace, workspace_bytes, B, H, W, 0, n_images);
     OFX_REQUIRE(ws.bytes <= workspace_bytes, OFX_ENOMEM);
     hipStream_t s = (hipStream_t)stream;
+    for (int e = 0; e < 3; ++e)
+        if (ws.sk[e]) OFX_HIP_CHECK(hipMemsetAsync(ws.sk[e], 0, 65536, s));
     const int h = H / 8, w = W / 8;
     const long N = (long)h * w;
     const int bgr = (flags & OFX_RAFT_BGR) ? 1 : 0;

@@ -240,7 +240,7 @@ def conv2d_nhwc(x: torch.Tensor, w_packed: torch.Tensor, kh: int, kw: int, cout:
                 shift: Optional[torch.Tensor] = None, scale: Optional[torch.Tensor] = None, act: Optional[str] = None,
                 x2: Optional[torch.Tensor] = None, res: Optional[torch.Tensor] = None,
                 nmean: Optional[torch.Tensor] = None, nrstd: Optional[torch.Tensor] = None, tile: int = 0,
-                precision: str = "fp32") -> torch.Tensor:
+                precision: str = "fp32", splitk_ws: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Plain-epilogue convolution: x [B,H,W,C0] (+ optional second channel segment x2 [B,H,W,C1]),
     'same' padding (k//2).  Returns [B,Hout,Wout,cout]."""
     x = _chk(x, "x", torch.float32)
@@ -268,6 +268,9 @@ def conv2d_nhwc(x: torch.Tensor, w_packed: torch.Tensor, kh: int, kw: int, cout:
     d.KH, d.KW, d.stride, d.padH, d.padW = kh, kw, stride, ph, pw
     d.act, d.epi, d.tile = ACTS[act], EPI_PLAIN, tile
     d.precision = {"fp32": 0, "bf16x3": 1, "bf16x3_w": 2}[precision]   # bf16x3_w: weight from split_conv_weight
+    if splitk_ws is not None:       # uint8 scratch whose first 64 KiB are zero (see ofx_conv_desc.splitk_ws): allows split-K
+        ws = _chk(splitk_ws, "splitk_ws", torch.uint8)
+        d.splitk_ws, d.splitk_ws_bytes = ws.data_ptr(), ws.numel()
     check(_lib.lib().ofx_conv2d(C.byref(d), _stream()), "ofx_conv2d")
     return out
 

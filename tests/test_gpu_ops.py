@@ -87,6 +87,31 @@ def test_conv2d_matches_torch(cuda, case):
     assert err < 2e-5, err      # fp32 accumulate, K <= 3456
 
 
+@pytest.mark.parametrize("case", [(1, 96, 64, 256, 256, 3, 3, "relu"), (1, 96, 64, 256, 128, 1, 5, "tanh"), (1, 50, 37, 128, 192, 3, 3, None),
+                                  (1, 20, 20, 256, 64, 3, 3, "relu")])
+def test_conv2d_split_k_small_grids(cuda, case):
+    """Grids of a few hundred 64x64 tiles are split along K over workgroups; the last one to arrive adds the parked
+    partial tiles and runs the epilogue.  Same result as the unsplit launch up to fp32 summation order, and the
+    arrival counters are left at zero so the scratch can be reused launch after launch."""
+    ops = _ops()
+    B, H, W, ci, co, kh, kw, act = case
+    g = torch.Generator().manual_seed(H * W + ci)
+    x = torch.randn((B, ci, H, W), generator=g)
+    w = torch.randn((co, ci, kh, kw), generator=g) / np.sqrt(ci * kh * kw)
+    b = torch.randn((co,), generator=g)
+    ref = F.conv2d(x, w, b, padding=(kh // 2, kw // 2))
+    ref = {"relu": torch.relu, "tanh": torch.tanh, None: lambda t: t}[act](ref)
+    wp = ops.pack_conv_weight(w).cuda()
+    ws = torch.zeros((65536 + 512 * 4 * 64 * 64 * 4,), dtype=torch.uint8, device="cuda")
+    plain = ops.conv2d_nhwc(nhwc(x), wp, kh, kw, co, shift=b.cuda(), act=act)
+    for _ in range(3):                                   # scratch reused without re-zeroing
+        out = ops.conv2d_nhwc(nhwc(x), wp, kh, kw, co, shift=b.cuda(), act=act, splitk_ws=ws)
+        assert (nchw(out) - ref).abs().max().item() < 2e-5
+        assert (out - plain).abs().max().item() < 1e-5
+    assert int(ws[:65536].view(torch.int32).abs().max()) == 0
+    assert not torch.equal(out, plain) or co == 64        # the split path really ran (different summation order)
+
+
 @pytest.mark.parametrize("case", [(2, 24, 20, 64, 64, 3, 3, 1), (1, 33, 17, 256, 256, 1, 5, 1), (1, 16, 16, 324, 256, 1, 1, 1),
                                   (1, 40, 24, 96, 192, 3, 3, 2)])
 def test_conv2d_bf16x3_mode(cuda, case):
