@@ -783,7 +783,7 @@ extern "C" int ofx_conv2d_alpha(const ofx_conv_desc* d, float alpha, void* strea
         // work per CU in tile units if the tiles are cut S ways: ceil(tiles * S / 256) / S -- take the S that
         // minimises it (ties: fewer splits), with at least six 32-wide chunks per split
         int S = 1;
-        if (tiles <= 512 && nk32 >= 12) {
+        if (tiles <= 1024 && nk32 >= 12) {
             double best = (double)((tiles + 255) / 256);
             for (int c = 2; c <= 4; ++c) {
                 if (nk32 / c < 6) break;

@@ -333,7 +333,7 @@ struct Streams {
     }
 };
 
-constexpr size_t SK_BYTES = 65536 + (size_t)512 * 4 * 64 * 64 * sizeof(float);   // counters + 512 tiles x 4 splits (conv.hip)
+constexpr size_t SK_BYTES = 65536 + (size_t)1024 * 4 * 64 * 64 * sizeof(float);   // counters + 1024 tiles x 4 splits (conv.hip)
 
 struct EncBufs {
     void* sk = nullptr;      // split-K scratch of the stream this encoder chain runs on
