@@ -206,7 +206,8 @@ long ofx_pack_conv_weight(const float* w_oihw, int Cout, int Cin, int KH, int KW
  * Same size as the input; use with precision = OFX_PREC_BF16X3_W. Returns 0 or OFX_EINVAL. */
 int ofx_split_conv_weight(const float* packed, long n_floats, float* out);
 
-/* instance norm statistics over HW per (b,c): mean and 1/sqrt(var+eps) (biased var), NHWC input */
+/* instance norm statistics over HW per (b,c): mean and 1/sqrt(var+eps) (biased var), NHWC input; C <= 256.
+ * scratch: max(B*64, min(B,7)*256) * C * 2 doubles (f64 partial sums per image slice), 8-byte aligned. */
 int ofx_inorm_stats(const float* x, int ld, float* mean, float* rstd, float* scratch,
                     int B, long HW, int C, float eps, void* stream);
 /* out = relu?( (x-mean)*rstd ) ; with res: out = relu( r + relu((x-mean)*rstd) ) where

@@ -25,10 +25,12 @@ __global__ __launch_bounds__(256) void preprocess_kernel(const uint8_t* __restri
 }
 
 // ---- instance-norm statistics: per (b, slice) partial sums in f64, then a finalize pass
-constexpr int kSlices = 64;
+// Slices per image: 64 fill the machine for a full encoder chunk; a handful of images (the single-pair
+// configuration) would leave most CUs idle in this reduction, so small batches are cut 4x finer.
+static inline int inorm_slices(int B) { return B >= 8 ? 64 : 256; }
 
 __global__ __launch_bounds__(256) void inorm_partial_kernel(const float* __restrict__ x, int ld, double* __restrict__ part,
-                                                            long HW, int C) {
+                                                            long HW, int C, int kSlices) {
     // grid: (kSlices, B).  Threads: (C/4) channel groups x rows.
     const int cg = C / 4;
     const int rows = 256 / cg;
@@ -66,17 +68,30 @@ __global__ __launch_bounds__(256) void inorm_partial_kernel(const float* __restr
     }
 }
 
+// one workgroup per (image, 16 channels): thread t sums the slices t / 16, t / 16 + 16, ... of channel t % 16, then the
+// 16 partial sums of a channel are added through LDS in a fixed order (deterministic)
 __global__ __launch_bounds__(256) void inorm_finalize_kernel(const double* __restrict__ part, float* __restrict__ mean,
-                                                             float* __restrict__ rstd, long HW, int C, int total, float eps) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;   // over B*C
-    if (i >= total) return;
-    const int b = i / C, c = i - b * C;
+                                                             float* __restrict__ rstd, long HW, int C, float eps, int kSlices) {
+    __shared__ double red[256 * 2];
+    const int b = blockIdx.y;
+    const int c = blockIdx.x * 16 + (threadIdx.x & 15), gsl = threadIdx.x >> 4;
     double s = 0, q = 0;
-    for (int sl = 0; sl < kSlices; ++sl) {
-        const double* o = part + (((long)b * kSlices + sl) * C + c) * 2;
-        s += o[0];
-        q += o[1];
+    if (c < C)
+        for (int sl = gsl; sl < kSlices; sl += 16) {
+            const double* o = part + (((long)b * kSlices + sl) * C + c) * 2;
+            s += o[0];
+            q += o[1];
+        }
+    red[threadIdx.x * 2] = s;
+    red[threadIdx.x * 2 + 1] = q;
+    __syncthreads();
+    if (threadIdx.x >= 16 || c >= C) return;
+    s = 0; q = 0;
+    for (int g2 = 0; g2 < 16; ++g2) {
+        s += red[(g2 * 16 + threadIdx.x) * 2];
+        q += red[(g2 * 16 + threadIdx.x) * 2 + 1];
     }
+    const int i = b * C + c;
     const double mu = s / (double)HW;
     double var = q / (double)HW - mu * mu;
     if (var < 0) var = 0;
@@ -253,19 +268,19 @@ int ofx_preprocess_u8(const uint8_t* img, float* out, long npix, int bgr, void* 
 int ofx_inorm_stats(const float* x, int ld, float* mean, float* rstd, float* scratch, int B, long HW, int C, float eps,
                     void* stream) {
     OFX_REQUIRE(x && mean && rstd && scratch && B > 0 && HW > 0 && C > 0, OFX_EINVAL);
-    OFX_REQUIRE(C % 4 == 0 && C / 4 <= 256 && ld % 4 == 0 && ld >= C && ofx_aligned16(x), OFX_EALIGN);
+    OFX_REQUIRE(C % 4 == 0 && C <= 256 && ld % 4 == 0 && ld >= C && ofx_aligned16(x), OFX_EALIGN);
     OFX_REQUIRE((((uintptr_t)scratch) & 7u) == 0, OFX_EALIGN);
     hipStream_t s = (hipStream_t)stream;
-    double* part = reinterpret_cast<double*>(scratch);   // needs B*kSlices*C*2 doubles
+    double* part = reinterpret_cast<double*>(scratch);   // needs B*slices*C*2 doubles (see ofx.h)
+    const int slices = inorm_slices(B);
     {
         OfxProfScope prof("inorm_stats", s);
-        hipLaunchKernelGGL(inorm_partial_kernel, dim3(kSlices, B), dim3(256), 0, s, x, ld, part, HW, C);
+        hipLaunchKernelGGL(inorm_partial_kernel, dim3(slices, B), dim3(256), 0, s, x, ld, part, HW, C, slices);
     }
     int st = ofx_launch_status();
     if (st) return st;
-    const int total = B * C;
     OfxProfScope prof("inorm_finalize", s);
-    hipLaunchKernelGGL(inorm_finalize_kernel, dim3(ofx_cdiv(total, 256)), dim3(256), 0, s, part, mean, rstd, HW, C, total, eps);
+    hipLaunchKernelGGL(inorm_finalize_kernel, dim3(ofx_cdiv(C, 16), B), dim3(256), 0, s, part, mean, rstd, HW, C, eps, slices);
     return ofx_launch_status();
 }
 

@@ -284,7 +284,7 @@ def inorm_stats(x: torch.Tensor, eps: float = 1e-5) -> Tuple[torch.Tensor, torch
     B, H, W, Cn = x.shape
     mean = torch.empty((B, Cn), dtype=torch.float32, device=x.device)
     rstd = torch.empty_like(mean)
-    scratch = torch.empty((B * 64 * Cn * 2,), dtype=torch.float64, device=x.device)
+    scratch = torch.empty((max(B * 64, min(B, 7) * 256) * Cn * 2,), dtype=torch.float64, device=x.device)
     check(_lib.lib().ofx_inorm_stats(_ptr(x), Cn, _ptr(mean), _ptr(rstd), _ptr(scratch), B, H * W, Cn, float(eps), _stream()),
           "ofx_inorm_stats")
     return mean, rstd
