@@ -38,6 +38,7 @@
 #include "ofx_internal.h"
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <type_traits>
 
@@ -449,7 +450,11 @@ __global__ __launch_bounds__(256 * KS, (BK == 16 && KS == 1) ? 3 : 1) void igemm
 #pragma unroll
                 for (int e = 0; e < 16; ++e)
                     __hip_atomic_store(mine + ((i * TN + j) * 16 + e) * 256 + tid, acc[i][j][e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");     // this wave's stores have been acknowledged
+        // Every wave must see its sc1 stores ACKNOWLEDGED (performed at agent scope) before the arrival counter moves.
+        // A workgroup-scope release fence does not wait for vmcnt on this target (waves of a workgroup share the
+        // L1), and an agent-scope one also writes the L2 back; the explicit wait is exactly what is needed.
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_s_waitcnt(0);                             // vmcnt(0) expcnt(0) lgkmcnt(0)
         __syncthreads();
         if (threadIdx.x == 0) {
             const int old = __hip_atomic_fetch_add(p.sk_count + tile_id, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -777,7 +782,8 @@ extern "C" int ofx_conv2d_alpha(const ofx_conv_desc* d, float alpha, void* strea
     // second round (384 tiles = 1.5 per CU: the makespan is 2 tiles); S splits make 384*S shorter work items that
     // balance.  Needs caller scratch: 64 KiB of counters + tiles * S * 64*64 floats.
     k.ksplit = 1; k.sk_part = nullptr; k.sk_count = nullptr;
-    if (d->splitk_ws && d->precision == OFX_PREC_FP32 && bm == 64 && bn == 64 && nz == 1 && d->tile == 0) {
+    static const bool dbg_no_sk = getenv("OFX_NO_SPLITK") != nullptr;
+    if (!dbg_no_sk && d->splitk_ws && d->precision == OFX_PREC_FP32 && bm == 64 && bn == 64 && nz == 1 && d->tile == 0) {
         const long tiles = (long)k.mtiles * k.ntiles;
         const int nk32 = (int)(k.Kpad / 32);
         // work per CU in tile units if the tiles are cut S ways: ceil(tiles * S / 256) / S -- take the S that

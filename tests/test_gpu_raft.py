@@ -187,3 +187,17 @@ def test_small_batch_stream_overlap_is_bit_identical_to_serial(engine):
         assert torch.equal(both, engine.forward(a, a.flip(0).contiguous(), iters=5, serial=True))
     out = engine.forward_pairs(torch.cat([key[None], frames]).cuda(), [1, 0], [0, 2], iters=6)
     assert torch.isfinite(out).all()
+
+
+def test_small_grids_repeat_bit_for_bit(engine):
+    """Split-K exchanges partial tiles between workgroups: a missing visibility wait shows up as run-to-run noise
+    (it did, once: a workgroup-scope release fence does not wait for the stores on this target).  Identical calls
+    must repeat exactly, in both schedules, at shapes where every layer of the update block is split."""
+    g = torch.Generator(device="cuda").manual_seed(0)
+    for (B, H, W, it) in ((2, 336, 280, 12), (3, 128, 160, 8), (1, 384, 256, 6)):
+        a = torch.randint(0, 256, (B, H, W, 3), dtype=torch.uint8, device="cuda", generator=g)
+        k = torch.randint(0, 256, (B, H, W, 3), dtype=torch.uint8, device="cuda", generator=g)
+        for serial in (False, True):
+            ref = engine.forward(a, k, iters=it, serial=serial).clone()
+            for _ in range(12):
+                assert torch.equal(engine.forward(a, k, iters=it, serial=serial), ref), (B, H, W, serial)
