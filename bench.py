@@ -397,9 +397,15 @@ def main():
             out["cpu_baseline"] = json.loads(r.stdout.strip().splitlines()[-1])
         except Exception as e:
             out["cpu_baseline"] = {"value": None, "unit": "pairs/s", "cores": usable_cores(), "kind": "port", "error": repr(e)[:200]}
-    print(json.dumps(out))
     if dist is not None:
-        dist.destroy_process_group()
+        dist.destroy_process_group()       # before the result line: RCCL prints its own banner lines on teardown
+    try:                                    # RCCL writes a banner through C stdio; flush it so that it cannot land
+        import ctypes                       # after the result line when stdout is a pipe
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    sys.stderr.flush()
+    print(json.dumps(out), flush=True)      # the ONE JSON line, last thing on stdout
 
 
 if __name__ == "__main__":
