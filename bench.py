@@ -188,6 +188,16 @@ def cpu_baseline(budget_s=15.0, max_pairs=24):   # a bounded sample: ~15-20 s of
             "sample": f"{done} pair(s) 512x768, RAFT {ITERS} iters fp32 + bilinear warp + mask, torch-CPU oracle, {dt:.1f} s"}
 
 
+def flush_c_stdio():
+    """RCCL / the HIP runtime write banner lines through C stdio; when stdout is a pipe they sit in a buffer until the
+    process exits and would land AFTER rank 0's result line (on any rank: torchrun merges the streams)."""
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -248,6 +258,7 @@ def main():
         step()
     prof = not args.no_prof
     barrier()
+    flush_c_stdio()                          # every rank: library banners out before anybody prints a result
     if prof:
         ops.prof_enable(True)
     t0 = time.perf_counter()
@@ -266,6 +277,7 @@ def main():
     if rank != 0:
         if dist is not None:
             dist.destroy_process_group()
+        flush_c_stdio()
         return
 
     ms_per_step = 1e3 * elapsed / args.steps
@@ -399,11 +411,7 @@ def main():
             out["cpu_baseline"] = {"value": None, "unit": "pairs/s", "cores": usable_cores(), "kind": "port", "error": repr(e)[:200]}
     if dist is not None:
         dist.destroy_process_group()       # before the result line: RCCL prints its own banner lines on teardown
-    try:                                    # RCCL writes a banner through C stdio; flush it so that it cannot land
-        import ctypes                       # after the result line when stdout is a pipe
-        ctypes.CDLL(None).fflush(None)
-    except Exception:
-        pass
+    flush_c_stdio()
     sys.stderr.flush()
     print(json.dumps(out), flush=True)      # the ONE JSON line, last thing on stdout
 
