@@ -3,5 +3,9 @@
 Drop-in for the `pdcnet_of.py` / `ofgen_*` call surface of zyddnys/sd_animation_optical_flow; all
 arithmetic runs in hand-written HIP kernels for gfx950 behind the C ABI of `libofx.so`
 (include/ofx.h).  There is no CPU fallback.
+
+Modules: `pdcnet_of`, `ofgen`, `alt_cuda_corr` (the reference's names), `raft` (the native executor's handle),
+`clip` (frame-parallel sharding + key-frame broadcast), `handoff` (SD-inpaint inputs on the device),
+`keyframes` (Canny-based key-frame detector), `ops` (one wrapper per C-ABI entry point), `_lib` (ctypes binding).
 """
 __version__ = "0.1.0"
