@@ -167,11 +167,36 @@ def pick_cpu_threads() -> int:
     return best
 
 
-def cpu_baseline(budget_s=15.0, max_pairs=24):   # a bounded sample: ~15-20 s of CPU work
+def verify_against_oracle(path):
+    """One pair of the timed batch (frame, key frame, AI key frame, confidence and the GPU's flow / warped / mask for it,
+    written by the bench process after the timed region) against the CPU oracle."""
+    import numpy as np
+    from oracle import mask_oracle, raft_oracle, warp_oracle
+    z = np.load(path)
+    sd = raft_oracle.init_state_dict(0)
+    a = torch.from_numpy(z["frame"]).permute(2, 0, 1)[None].float()
+    b = torch.from_numpy(z["key"]).permute(2, 0, 1)[None].float()
+    t0 = time.time()
+    _, up = raft_oracle.raft_forward(sd, a, b, iters=ITERS)
+    ref = up[0].permute(1, 2, 0).contiguous().numpy()
+    d = z["flow"] - ref
+    epe = float(np.sqrt((d * d).sum(-1)).mean())
+    wref = warp_oracle.warp_frame(z["key_ai"], z["flow"], mode=str(z["warp_mode"]))
+    wd = np.abs(wref.astype(np.int32) - z["warped"].astype(np.int32))
+    mref, _ = mask_oracle.generate_mask(z["conf"], z["conf"].copy(), 0.95, 7)
+    return {"pair": int(z["index"]), "flow_epe_px": epe, "flow_max_err_px": float(np.sqrt((d * d).sum(-1)).max()),
+            "warp_max_abs_diff_u8": int(wd.max()), "warp_frac_pixels_differing": float((wd > 0).mean()),
+            "mask_bit_exact": bool(np.array_equal(mref, z["mask"])), "oracle_s": round(time.time() - t0, 2)}
+
+
+def cpu_baseline(budget_s=15.0, max_pairs=24, verify=None):   # a bounded sample: ~15-20 s of CPU work
     """The CPU oracle (port of the reference's path) on the host cores: flow + warp + mask per pair."""
     from oracle import mask_oracle, raft_oracle, warp_oracle
     threads = pick_cpu_threads()
     torch.set_num_threads(threads)
+    out = {}
+    if verify:
+        out["verified"] = verify_against_oracle(verify)
     sd = raft_oracle.init_state_dict(0)
     frames, key, key_ai, conf = make_clip(max_pairs, H, W, "cpu")
     done, t0 = 0, time.time()
@@ -184,8 +209,9 @@ def cpu_baseline(budget_s=15.0, max_pairs=24):   # a bounded sample: ~15-20 s of
         mask_oracle.generate_mask(conf[done].numpy(), conf[done].numpy().copy(), 0.95, 7)
         done += 1
     dt = time.time() - t0
-    return {"value": done / dt, "unit": "pairs/s", "cores": threads, "kind": "port",
-            "sample": f"{done} pair(s) 512x768, RAFT {ITERS} iters fp32 + bilinear warp + mask, torch-CPU oracle, {dt:.1f} s"}
+    out.update({"value": done / dt, "unit": "pairs/s", "cores": threads, "kind": "port",
+                "sample": f"{done} pair(s) 512x768, RAFT {ITERS} iters fp32 + bilinear warp + mask, torch-CPU oracle, {dt:.1f} s"})
+    return out
 
 
 def flush_c_stdio():
@@ -198,6 +224,38 @@ def flush_c_stdio():
         pass
 
 
+def self_launch(args):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it: start N ranks ourselves (one process per GPU
+    under torch.distributed.run, RCCL rendezvous on 127.0.0.1) instead of measuring one GPU under a label that says N."""
+    have = torch.cuda.device_count()
+    if have < args.gpus and not args.stub_step:
+        print(f"bench.py: --gpus {args.gpus} asked for but only {have} HIP device(s) are visible; refusing to measure "
+              f"fewer GPUs than requested", file=sys.stderr)
+        sys.exit(2)
+    import socket
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    os.execv(sys.executable, cmd)
+
+
+def stub_step_factory(dev):
+    """CPU stand-in for the hot path (hidden --stub-step): lets the world_size-2 gloo test drive every line of the
+    rank plumbing (init, key-frame broadcast, barrier, timed loop, MAX all-reduce, one JSON line) without a GPU."""
+    from sd_animation_optical_flow_amd import clip
+    key = torch.zeros((8, 8, 3), dtype=torch.uint8, device=dev)
+    key_ai = torch.zeros_like(key)
+
+    def step():
+        clip.broadcast_keyframe([key, key_ai], src=0)
+        time.sleep(0.01)
+        return None
+    return step
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -207,68 +265,101 @@ def main():
     ap.add_argument("--warp-mode", default="bilinear", choices=["bilinear", "bicubic", "cv2_cubic"])
     ap.add_argument("--no-prof", action="store_true", help="do not bracket launches with HIP events")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-verify", action="store_true", help="skip the oracle check of one sampled pair")
     ap.add_argument("--no-single", action="store_true")
     ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16x3"],
                     help="matrix-core arithmetic of the timed run (fp32 = the reference's; bf16x3 = opt-in split-bf16 fast mode)")
     ap.add_argument("--no-fast", action="store_true", help="skip the secondary bf16x3 measurement")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--verify-npz", default=None, help=argparse.SUPPRESS)
+    ap.add_argument("--verify-only", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--stub-step", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.cpu_baseline_only:
-        print(json.dumps(cpu_baseline()))
+        print(json.dumps(cpu_baseline(verify=args.verify_npz)))
+        return
+    if args.verify_only:
+        torch.set_num_threads(pick_cpu_threads())
+        print(json.dumps({"verified": verify_against_oracle(args.verify_npz)}))
         return
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args)                    # does not return
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        # a launcher that started a different number of ranks than the command line names: the line would be mislabelled
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; start it as `python bench.py --gpus N` or under "
+              f"torch.distributed.run with --nproc-per-node N", file=sys.stderr)
+        sys.exit(2)
+    backend = "gloo" if args.stub_step else "nccl"
     # OFX_BENCH_FORCE_DIST=1 exercises the RCCL code path (init, broadcast, barrier, all-reduce) on one rank
     use_dist = world > 1 or (os.environ.get("OFX_BENCH_FORCE_DIST") == "1" and "MASTER_PORT" in os.environ)
+    if not args.stub_step and torch.cuda.device_count() <= local_rank:
+        print(f"bench.py: rank {rank} needs HIP device {local_rank} but only {torch.cuda.device_count()} are visible", file=sys.stderr)
+        sys.exit(2)
+    dev = torch.device("cpu") if args.stub_step else torch.device("cuda", local_rank if use_dist else 0)
     if use_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.stub_step:
+            dist.init_process_group(backend)
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group(backend, device_id=dev)
     else:
         dist = None
-        torch.cuda.set_device(0)
-    dev = torch.device("cuda", local_rank if use_dist else 0)
-    n_gpus = world if world > 1 else 1
-    if args.gpus != n_gpus and rank == 0:
-        print(f"# note: --gpus {args.gpus} but WORLD_SIZE={world}; using {n_gpus}", file=sys.stderr)
-
-    from sd_animation_optical_flow_amd import clip, ops
-    from sd_animation_optical_flow_amd.raft import RaftEngine
-    from sd_animation_optical_flow_amd.weights import random_state_dict
+        if not args.stub_step:
+            torch.cuda.set_device(0)
+    n_gpus = world
+    sync = (lambda: None) if args.stub_step else torch.cuda.synchronize
 
     B = args.batch
-    eng = RaftEngine(random_state_dict(0), dev, precision=args.precision)
-    frames, key, key_ai, conf = make_clip(B, H, W, dev, rank)
+    if args.stub_step:
+        step = stub_step_factory(dev)
+        ops = None
+    else:
+        from sd_animation_optical_flow_amd import clip, ops
+        from sd_animation_optical_flow_amd.raft import RaftEngine
+        from sd_animation_optical_flow_amd.weights import random_state_dict
+        eng = RaftEngine(random_state_dict(0), dev, precision=args.precision)
+        frames, key, key_ai, conf = make_clip(B, H, W, dev, rank)
 
-    def step():
-        clip.broadcast_keyframe([key, key_ai], src=0)                 # the path's only exchange
-        flow = eng.forward(frames, key, iters=ITERS)                  # frame -> key frame, shared image2
-        warped, mask = ops.warp_and_mask(key_ai, flow, conf, warp_mode=args.warp_mode, thres=0.95, ksize=7)
-        return flow, warped, mask
+        def step():
+            clip.broadcast_keyframe([key, key_ai], src=0)                 # the path's only exchange
+            flow = eng.forward(frames, key, iters=ITERS)                  # frame -> key frame, shared image2
+            warped, mask = ops.warp_and_mask(key_ai, flow, conf, warp_mode=args.warp_mode, thres=0.95, ksize=7)
+            return flow, warped, mask
 
     def barrier():
         if dist is not None:
             dist.barrier()
-        torch.cuda.synchronize()
+        sync()
+
+    # how many ranks the collective library actually sees (RCCL's own count, not the environment's)
+    ranks_seen = 1
+    if dist is not None:
+        one = torch.ones((1,), device=dev, dtype=torch.float32)
+        dist.all_reduce(one)
+        ranks_seen = int(round(float(one.item())))
 
     for _ in range(args.warmup):
         step()
-    prof = not args.no_prof
+    prof = not args.no_prof and ops is not None
     barrier()
     flush_c_stdio()                          # every rank: library banners out before anybody prints a result
     if prof:
-        ops.prof_enable(True)
+        ops.prof_enable(2)                   # per layer ("family:layer"); families are re-aggregated below
+    last = None
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        step()
+        last = step()
     barrier()
     elapsed = time.perf_counter() - t0
-    kern = {}
+    layers = {}
     if prof:
-        kern = ops.prof_collect()
+        layers = ops.prof_collect()
         ops.prof_enable(False)
     if dist is not None:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
@@ -285,13 +376,29 @@ def main():
     work = algorithmic_work(H, W, B)
     out = {
         "metric": "frame-pairs/sec (flow+warp+mask) at 512x768",
-        "value": round(value, 3), "unit": "pairs/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
+        "value": round(value, 3), "unit": "pairs/s", "n_gpus": n_gpus, "ranks_seen": ranks_seen, "steps": args.steps,
+        "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32" if args.precision == "fp32" else "bf16x3 (fp32 operands split into two bf16, fp32 accumulate)", "data": "synthetic",
         "config": {"workload": f"BASELINE configs[2]: {B}-frame 512x768 clip per GPU vs one shared key frame, RAFT {ITERS} iters "
                                f"fp32 + {args.warp_mode} warp + mask(conf<0.95, 7x7); configs[3] sharding at N>1",
                    "frames_per_gpu": B, "H": H, "W": W, "iters": ITERS, "parallelism": f"frame-parallel x{n_gpus}"},
     }
+    if args.stub_step:
+        out["data"] = "stub step (rank-plumbing test, no GPU work)"
+        if dist is not None:
+            dist.destroy_process_group()
+        print(json.dumps(out), flush=True)
+        return
+
+    # families = launches grouped by kernel name ("family:layer" -> "family")
+    kern = {}
+    for name, v in layers.items():
+        fam = name.split(":", 1)[0]
+        k = kern.setdefault(fam, {"calls": 0, "ms": 0.0, "flops": 0.0})
+        k["calls"] += v["calls"]
+        k["ms"] += v["ms"]
+        k["flops"] += v.get("flops", 0.0)
 
     def per_launch(names):
         ms = sum(kern[n]["ms"] for n in names if n in kern)
@@ -303,16 +410,21 @@ def main():
         ms, calls = per_launch(conv_names)
         steps = args.steps
         if ms > 0:
-            tf = work["conv_flops"] * steps / (ms * 1e-3) / 1e12
+            executed = sum(kern[n]["flops"] for n in conv_names if n in kern)       # what the launches really multiplied
+            if executed <= 0:
+                executed = work["conv_flops_executed"] * steps
+            tf_exec = executed / (ms * 1e-3) / 1e12
+            tf_alg = work["conv_flops"] * steps / (ms * 1e-3) / 1e12
             out["roofline"] = {"bound": "mfma", "kernel": "igemm_kernel (fp32 MFMA implicit-GEMM conv, all epilogues)",
-                               "achieved": round(tf, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                               "frac": round(tf / MFMA_F32_PEAK_TFLOPS, 4), "traffic": None,
+                               "achieved": round(tf_exec, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                               "frac": round(tf_exec / MFMA_F32_PEAK_TFLOPS, 4), "traffic": None,
                                "launches_per_step": calls // steps, "avg_launch_ms": round(ms / calls, 4),
-                               "flops_per_step": work["conv_flops"], "share_of_step": round(ms / steps / ms_per_step, 4),
-                               "executed_tflops": round(work["conv_flops_executed"] * steps / (ms * 1e-3) / 1e12, 2),
-                               "executed_frac": round(work["conv_flops_executed"] * steps / (ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS, 4),
-                               "note": "achieved = algorithmic FLOPs of the reference's convolutions / measured kernel time; "
-                                       "executed_* discounts the GRU context term hoisted out of the 20-iteration loop"}
+                               "flops_per_step_executed": executed / steps, "share_of_step": round(ms / steps / ms_per_step, 4),
+                               "algorithmic_tflops": round(tf_alg, 2), "algorithmic_flops_per_step": work["conv_flops"],
+                               "note": "achieved/frac = FLOPs the launches executed / HIP-event kernel time / fp32-MFMA peak; "
+                                       "algorithmic_tflops prices the reference's convolution FLOPs (SURVEY 8d) instead: the GRU's "
+                                       "loop-invariant context third is evaluated once per pair, an algorithmic saving, not "
+                                       "hardware efficiency"}
         ks = {}
 
         def hbm(name, key_bytes, label):
@@ -335,24 +447,24 @@ def main():
             tfv = work["volume_flops"] * steps / (m * 1e-3) / 1e12
             ks["corr_volume_gemm"]["tflops"] = round(tfv, 2)
             ks["corr_volume_gemm"]["mfma_frac"] = round(tfv / MFMA_F32_PEAK_TFLOPS, 4)
-        # HBM bytes per launch from the committed PMC passes of this same command (rocprofv3 --pmc FETCH_SIZE /
-        # WRITE_SIZE in separate runs; FETCH_SIZE doubled per the gfx950 correction, calibrated on the pooling
-        # kernel: corrected 12.83 GB = its exact algorithmic 12.83 GB).  PMC cannot be collected inside this run.
+        # HBM bytes per launch: PMC counters cannot be read from inside this process, so `traffic` is the figure of the
+        # committed rocprofv3 --pmc passes of this same command (FETCH_SIZE / WRITE_SIZE in separate runs, corrected per
+        # access width with the calibration kernels of tools/pmc_calibrate.py) and is labelled as such.
         import glob
         tps = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic_b64.json")))   # newest round last
         if B == 64 and tps:
             tp = tps[-1]
             tr = json.load(open(tp))
+            src = f"profile: profiles/{os.path.basename(tp)} (committed rocprofv3 --pmc passes, not collected in this run)"
             if "roofline" in out and "igemm_conv_all" in tr:
                 out["roofline"]["traffic"] = tr["igemm_conv_all"]["hbm_bytes_per_launch_corrected"]
-                out["roofline"]["traffic_source"] = f"profiles/{os.path.basename(tp)} (avg over all convolution launches)"
+                out["roofline"]["traffic_source"] = src
             for label, tkey in (("corr_volume_gemm", "corr_volume_gemm"), ("corr_lookup", "corr_lookup"),
                                ("corr_pyramid_pool", "pyramid_pool"), ("upsample_flow", "upsample"),
                                ("warp", "warp"), ("mask", "mask")):
                 if label in ks and tkey in tr:
                     ks[label]["traffic"] = tr[tkey]["hbm_bytes_per_launch_corrected"]
-                    # bytes the memory system actually moved (PMC) over the measured launch time: how hard the kernel
-                    # drives HBM, as opposed to `frac` (algorithmic bytes: how much of that traffic was necessary)
+                    ks[label]["traffic_source"] = "profile"
                     if ks[label].get("avg_launch_ms"):
                         gbs = ks[label]["traffic"] / (ks[label]["avg_launch_ms"] * 1e-3) / 1e9
                         ks[label]["traffic_gbs"] = round(gbs, 1)
@@ -360,6 +472,29 @@ def main():
         out["kernels"] = ks
         tot = sum(v["ms"] for v in kern.values())
         out["kernel_time_share"] = {k: round(v["ms"] / tot, 4) for k, v in sorted(kern.items(), key=lambda kv: -kv[1]["ms"])[:8]}
+        # per-layer table of the convolutions (executed TFLOP/s per layer: the short-K layers are the visible deficit)
+        rows = []
+        for name, v in layers.items():
+            if ":" in name and v.get("flops", 0) > 0 and name.split(":", 1)[0] in conv_names + ["igemm_corr_volume"]:
+                rows.append({"layer": name.split(":", 1)[1], "calls_per_step": v["calls"] // steps,
+                             "avg_ms": round(v["ms"] / v["calls"], 4), "ms_per_step": round(v["ms"] / steps, 3),
+                             "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1)})
+        rows.sort(key=lambda r: -r["ms_per_step"])
+        out["layers"] = rows[:40]
+
+    verify_path = None
+    if not args.no_verify and last is not None:
+        # one pair of the LAST timed step, checked against the CPU oracle outside the timed region
+        import tempfile
+        import numpy as np
+        vb = B // 2
+        flow, warped, mask = last
+        fd, verify_path = tempfile.mkstemp(suffix=".npz", prefix="ofx_verify_")
+        os.close(fd)
+        np.savez(verify_path, frame=frames[vb].cpu().numpy(), key=key.cpu().numpy(), key_ai=key_ai.cpu().numpy(),
+                 conf=conf[vb].cpu().numpy(), flow=flow[vb].cpu().numpy(), warped=warped[vb].cpu().numpy(),
+                 mask=mask[vb].cpu().numpy(), index=vb, warp_mode=args.warp_mode)
+    del last
 
     if not args.no_single and world == 1:
         f1 = frames[:1].contiguous()
@@ -400,15 +535,31 @@ def main():
                             "note": "opt-in; not the headline value (the reference computes in fp32)"}
         del fast, ref_flow
 
-    if not args.no_cpu_baseline and world == 1:
-        # child process with a hard time limit: the baseline must never take the GPU number down with it
-        import subprocess
+    # child process with a hard time limit: neither the baseline nor the check may take the GPU number down with them
+    import subprocess
+    want_base = not args.no_cpu_baseline and world == 1
+    if want_base or verify_path:
+        cmd = [sys.executable, os.path.abspath(__file__)]
+        cmd += ["--cpu-baseline-only"] if want_base else ["--verify-only"]
+        if verify_path:
+            cmd += ["--verify-npz", verify_path]
         try:
-            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-only"], capture_output=True, text=True,
-                               timeout=240, env=dict(os.environ, HIP_VISIBLE_DEVICES=""))
-            out["cpu_baseline"] = json.loads(r.stdout.strip().splitlines()[-1])
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=dict(os.environ, HIP_VISIBLE_DEVICES=""))
+            res = json.loads(r.stdout.strip().splitlines()[-1])
+            ver = res.pop("verified", None)
+            if want_base:
+                out["cpu_baseline"] = res
+            if ver is not None:
+                out["verified"] = ver
+                out["verified_epe"] = ver["flow_epe_px"]
         except Exception as e:
-            out["cpu_baseline"] = {"value": None, "unit": "pairs/s", "cores": usable_cores(), "kind": "port", "error": repr(e)[:200]}
+            if want_base:
+                out["cpu_baseline"] = {"value": None, "unit": "pairs/s", "cores": usable_cores(), "kind": "port", "error": repr(e)[:200]}
+            if verify_path:
+                out["verified"] = {"error": repr(e)[:200]}
+        finally:
+            if verify_path and os.path.exists(verify_path):
+                os.unlink(verify_path)
     if dist is not None:
         dist.destroy_process_group()       # before the result line: RCCL prints its own banner lines on teardown
     flush_c_stdio()

@@ -126,12 +126,17 @@ def gaps(fps: float, min_gap: int = -1, max_gap: int = -1) -> tuple:
     return mn, mx
 
 
-def keyframe_flags(frames, fps: float = 30.0, th: float = 8.5, min_gap: int = -1, max_gap: int = -1) -> list:
-    """The decisions of frame_generator (:342-368) for an already decoded / resized frame sequence (keep_every = 1)."""
+def keyframe_flags(frames, fps: float = 30.0, th: float = 8.5, min_gap: int = -1, max_gap: int = -1,
+                   keep_every: int = 1) -> list:
+    """The decisions of frame_generator (:342-368) for an already decoded / resized frame sequence: one flag per KEPT
+    frame (`ctr % keep_every == 0`, :351).  `gap` counts every decoded frame: the reference increments it (:347)
+    before the keep_every filter (:351-352)."""
     _, mx = gaps(fps, min_gap, max_gap)
     flags, key_edges, gap, ksize = [], None, 0, None
-    for frame in frames:
+    for ctr, frame in enumerate(frames):
         gap += 1
+        if ctr % keep_every != 0:
+            continue
         if ksize is None:
             ksize = estimated_kernel_size(frame.shape[1], frame.shape[0])
         edges = detect_edges(frame, ksize)

@@ -36,8 +36,12 @@ struct Cv2Tables {
     short* i = nullptr;   // [1024][16]
     int status = 0;
 };
-Cv2Tables g_tabs;
-std::once_flag g_tabs_once;
+// One table set per HIP device: the tables live in that device's memory, so a process that moves its algorithm
+// to another GPU (`PDCNetPlus.to(device)`) must not hand device 0's pointers to a kernel running on device 1.
+constexpr int kMaxDevices = 64;
+Cv2Tables g_tabs_dev[kMaxDevices];
+bool g_tabs_built[kMaxDevices] = {};
+std::mutex g_tabs_mu;
 
 void host_cubic(float x, float* c) {
     const float A = -0.75f;
@@ -64,7 +68,7 @@ void host_cubic(float x, float* c) {
     c[3] = e1 - c[2];
 }
 
-void build_tables() {
+void build_tables(Cv2Tables& tabs) {
     std::vector<float> c1(kTabSize * 4);
     for (int i = 0; i < kTabSize; ++i) host_cubic((float)i * (1.0f / kTabSize), &c1[i * 4]);
     std::vector<float> tf(kTabSize * kTabSize * 16);
@@ -98,16 +102,25 @@ void build_tables() {
                 else it[mk] = (short)(it[mk] - diff);
             }
         }
-    hipError_t e = hipMalloc(&g_tabs.f, tf.size() * sizeof(float));
-    if (e == hipSuccess) e = hipMalloc(&g_tabs.i, ti.size() * sizeof(short));
-    if (e == hipSuccess) e = hipMemcpy(g_tabs.f, tf.data(), tf.size() * sizeof(float), hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = hipMemcpy(g_tabs.i, ti.data(), ti.size() * sizeof(short), hipMemcpyHostToDevice);
-    g_tabs.status = (int)e;
+    hipError_t e = hipMalloc(&tabs.f, tf.size() * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc(&tabs.i, ti.size() * sizeof(short));
+    if (e == hipSuccess) e = hipMemcpy(tabs.f, tf.data(), tf.size() * sizeof(float), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(tabs.i, ti.data(), ti.size() * sizeof(short), hipMemcpyHostToDevice);
+    tabs.status = (int)e;
 }
 
-int ensure_tables() {
-    std::call_once(g_tabs_once, build_tables);
-    return g_tabs.status;
+// Tables of the CURRENT device (the one the caller's stream and pointers belong to), built on first use.
+int ensure_tables(const Cv2Tables** out) {
+    int dev = 0;
+    OFX_HIP_CHECK(hipGetDevice(&dev));
+    OFX_REQUIRE(dev >= 0 && dev < kMaxDevices, OFX_ENODEV);
+    std::lock_guard<std::mutex> lk(g_tabs_mu);
+    if (!g_tabs_built[dev]) {
+        build_tables(g_tabs_dev[dev]);
+        g_tabs_built[dev] = g_tabs_dev[dev].status == 0;
+    }
+    *out = &g_tabs_dev[dev];
+    return g_tabs_dev[dev].status;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -544,11 +557,9 @@ __global__ __launch_bounds__(256) void warp_bilinear_u8c3_kernel(const BilinArgs
 
 template <typename T, int C>
 int launch_warp_c(const T* frame, long fbs, const float* flow, T* out, int B, int H, int W, int mode,
-                  float sign, hipStream_t s) {
+                  float sign, const short* ti, const float* tf, hipStream_t s) {
     const long total = (long)B * H * W;
     const int grid = (int)std::min<long>((total + 255) / 256, 256L * 32);
-    const short* ti = g_tabs.i;
-    const float* tf = g_tabs.f;
     OfxProfScope prof(sizeof(T) == 1 ? "warp_u8" : "warp_f32", s);
     switch (mode) {
         case OFX_WARP_BILINEAR:
@@ -572,9 +583,14 @@ int launch_warp(const T* frame, long fbs, const float* flow, T* out, int B, int 
     OFX_REQUIRE(B > 0 && H > 0 && W > 0 && C >= 1 && C <= 4, OFX_EINVAL);
     OFX_REQUIRE(mode >= 0 && mode <= 2, OFX_EINVAL);
     OFX_REQUIRE((((uintptr_t)flow) & 7u) == 0, OFX_EALIGN);
+    const short* tabs_i = nullptr;
+    const float* tabs_f = nullptr;
     if (mode == OFX_WARP_CV2_CUBIC) {
-        int st = ensure_tables();
+        const Cv2Tables* t = nullptr;
+        int st = ensure_tables(&t);
         if (st) return st;
+        tabs_i = t->i;
+        tabs_f = t->f;
     }
     hipStream_t s = (hipStream_t)stream;
     const long npix = (long)B * H * W;
@@ -603,17 +619,17 @@ int launch_warp(const T* frame, long fbs, const float* flow, T* out, int B, int 
         OfxProfScope prof("warp_u8", s);
         if (mode == OFX_WARP_BILINEAR)
             hipLaunchKernelGGL((warp_u8c3_x4_kernel<OFX_WARP_BILINEAR>), dim3(grid), dim3(256), 0, s, (const uint8_t*)frame, fbs, flow,
-                               (uint8_t*)out, H, W, ngroups, sign, g_tabs.i);
+                               (uint8_t*)out, H, W, ngroups, sign, tabs_i);
         else
             hipLaunchKernelGGL((warp_u8c3_x4_kernel<OFX_WARP_CV2_CUBIC>), dim3(grid), dim3(256), 0, s, (const uint8_t*)frame, fbs, flow,
-                               (uint8_t*)out, H, W, ngroups, sign, g_tabs.i);
+                               (uint8_t*)out, H, W, ngroups, sign, tabs_i);
         return ofx_launch_status();
     }
     switch (C) {
-        case 1: return launch_warp_c<T, 1>(frame, fbs, flow, out, B, H, W, mode, sign, s);
-        case 2: return launch_warp_c<T, 2>(frame, fbs, flow, out, B, H, W, mode, sign, s);
-        case 3: return launch_warp_c<T, 3>(frame, fbs, flow, out, B, H, W, mode, sign, s);
-        default: return launch_warp_c<T, 4>(frame, fbs, flow, out, B, H, W, mode, sign, s);
+        case 1: return launch_warp_c<T, 1>(frame, fbs, flow, out, B, H, W, mode, sign, tabs_i, tabs_f, s);
+        case 2: return launch_warp_c<T, 2>(frame, fbs, flow, out, B, H, W, mode, sign, tabs_i, tabs_f, s);
+        case 3: return launch_warp_c<T, 3>(frame, fbs, flow, out, B, H, W, mode, sign, tabs_i, tabs_f, s);
+        default: return launch_warp_c<T, 4>(frame, fbs, flow, out, B, H, W, mode, sign, tabs_i, tabs_f, s);
     }
 }
 
@@ -893,20 +909,25 @@ int ofx_travel_mask(const float* conf, const float* flow, const float* dist, con
                     float* travel_out, uint8_t* raw, int B, int H, int W, float thres, int warp_mode, void* stream) {
     OFX_REQUIRE(conf && flow && dist && travel_in && travel_out && raw && travel_in != travel_out, OFX_EINVAL);
     OFX_REQUIRE(B > 0 && H > 0 && W > 0 && warp_mode >= 0 && warp_mode <= 2, OFX_EINVAL);
+    const short* tabs_i = nullptr;
+    const float* tabs_f = nullptr;
     if (warp_mode == OFX_WARP_CV2_CUBIC) {
-        int st = ensure_tables();
+        const Cv2Tables* t = nullptr;
+        int st = ensure_tables(&t);
         if (st) return st;
+        tabs_i = t->i;
+        tabs_f = t->f;
     }
     const long total = (long)B * H * W;
     hipStream_t s = (hipStream_t)stream;
     const int g = grid_for(total);
     OfxProfScope prof("travel_mask", s);
     if (warp_mode == OFX_WARP_BILINEAR)
-        hipLaunchKernelGGL((travel_mask_kernel<OFX_WARP_BILINEAR>), dim3(g), dim3(256), 0, s, conf, flow, dist, travel_in, travel_out, raw, H, W, total, thres, g_tabs.i, g_tabs.f);
+        hipLaunchKernelGGL((travel_mask_kernel<OFX_WARP_BILINEAR>), dim3(g), dim3(256), 0, s, conf, flow, dist, travel_in, travel_out, raw, H, W, total, thres, tabs_i, tabs_f);
     else if (warp_mode == OFX_WARP_BICUBIC)
-        hipLaunchKernelGGL((travel_mask_kernel<OFX_WARP_BICUBIC>), dim3(g), dim3(256), 0, s, conf, flow, dist, travel_in, travel_out, raw, H, W, total, thres, g_tabs.i, g_tabs.f);
+        hipLaunchKernelGGL((travel_mask_kernel<OFX_WARP_BICUBIC>), dim3(g), dim3(256), 0, s, conf, flow, dist, travel_in, travel_out, raw, H, W, total, thres, tabs_i, tabs_f);
     else
-        hipLaunchKernelGGL((travel_mask_kernel<OFX_WARP_CV2_CUBIC>), dim3(g), dim3(256), 0, s, conf, flow, dist, travel_in, travel_out, raw, H, W, total, thres, g_tabs.i, g_tabs.f);
+        hipLaunchKernelGGL((travel_mask_kernel<OFX_WARP_CV2_CUBIC>), dim3(g), dim3(256), 0, s, conf, flow, dist, travel_in, travel_out, raw, H, W, total, thres, tabs_i, tabs_f);
     return ofx_launch_status();
 }
 

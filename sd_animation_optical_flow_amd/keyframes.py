@@ -62,23 +62,28 @@ def gaps(fps: float, min_gap: int = -1, max_gap: int = -1) -> Tuple[int, int]:
 
 
 def frame_generator(frames: Iterable, fps: float = 30.0, th: float = 8.5, min_gap: int = -1, max_gap: int = -1,
-                    batch: int = 16, device="cuda") -> Iterator[Tuple[object, bool, int]]:
-    """The decision loop of the reference's `frame_generator` (:342-368) over already decoded and resized frames
-    (numpy or tensors, BGR uint8 [H,W,3]): yields (frame, is_keyframe, index).  Edge maps are computed `batch`
-    frames at a time on the device; the sequential part is one small reduction per frame."""
+                    batch: int = 16, device="cuda", keep_every: int = 1,
+                    max_decoded: int = 60 * 60) -> Iterator[Tuple[object, bool, int]]:
+    """The decision loop of the reference's `frame_generator` (:342-368).  `frames` iterates over EVERY decoded frame
+    (numpy or tensors, BGR uint8 [H,W,3], already resized); only every `keep_every`-th one is examined and yielded as
+    (frame, is_keyframe, index-among-kept-frames), but -- as in the reference, which does `gap += 1` before its
+    `ctr % keep_every` filter (:346-352) -- the gap that relaxes the threshold counts decoded frames, dropped ones
+    included.  Stops after the frame with decoded index `max_decoded` (:366-367).  Edge maps are computed `batch`
+    kept frames at a time on the device; the sequential part is one small reduction per frame."""
     _, mx = gaps(fps, min_gap, max_gap)
+    keep_every = max(1, int(keep_every))
     key_edges, gap, ksize, idx = None, 0, None, -1
-    buf: List = []
+    buf: List = []          # (frame, decoded frames since the previous kept frame)
 
     def flush(buf):
         nonlocal key_edges, gap, ksize, idx
-        dev = torch.stack([_dev(f, device) for f in buf])
+        dev = torch.stack([_dev(f, device) for f, _ in buf])
         if ksize is None:
             ksize = estimated_kernel_size(dev.shape[2], dev.shape[1])
         edges = ops.detect_edges(dev, ksize)
-        for j, frame in enumerate(buf):
+        for j, (frame, inc) in enumerate(buf):
             idx += 1
-            gap += 1
+            gap += inc
             if key_edges is None:
                 key_edges = edges[j]
                 yield frame, True, idx
@@ -90,10 +95,16 @@ def frame_generator(frames: Iterable, fps: float = 30.0, th: float = 8.5, min_ga
             else:
                 yield frame, False, idx
 
-    for frame in frames:
-        buf.append(frame)
-        if len(buf) == batch:
-            yield from flush(buf)
-            buf = []
+    pending = 0
+    for ctr, frame in enumerate(frames):
+        pending += 1
+        if ctr % keep_every == 0:
+            buf.append((frame, pending))
+            pending = 0
+            if len(buf) == batch:
+                yield from flush(buf)
+                buf = []
+        if ctr >= max_decoded:
+            break
     if buf:
         yield from flush(buf)

@@ -66,8 +66,10 @@ class PDCNetPlus:
         by the batch).  Returns (flow f32[B,H,W,2] on the target grid pointing into source, confidence
         f32[B,H,W], log_confidence f32[B,H,W]) -- all on the device."""
         net = self.network
+        H0, W0 = target.shape[-3], target.shape[-2]
         if not want_confidence:
-            return net.forward(target, source, iters=self.iters, bgr=bgr), None, None          # target -> source
+            flow = net.forward(target, source, iters=self.iters, bgr=bgr)                      # target -> source
+            return _unpad(flow, H0, W0), None, None
         # Both directions in ONE indexed-pairs call: every image is encoded once (two separate forwards encode each
         # image twice) and the forward / backward refinements share their launches (2B pairs per batch).
         shared = source.dim() == 3
@@ -89,8 +91,10 @@ class PDCNetPlus:
             fss.append(out[n:])                                # on the source grid, pointing into the target
         flow_t = fts[0] if len(fts) == 1 else torch.cat(fts)
         flow_s = fss[0] if len(fss) == 1 else torch.cat(fss)
+        # the consistency check runs on the padded grids (both flows live there); the reference's `calc` promises
+        # [H,W] outputs (pdcnet_of.py:72-75), so the replicate padding is cropped away afterwards
         conf, logc = ops.fb_confidence(flow_t.contiguous(), flow_s.contiguous(), self.sigma)
-        return flow_t, conf, logc
+        return _unpad(flow_t, H0, W0), _unpad(conf, H0, W0), _unpad(logc, H0, W0)
 
     @torch.no_grad()
     def calc_pairs(self, frames: torch.Tensor, pairs, bgr: bool = False, max_flows: int = 64):
@@ -100,7 +104,10 @@ class PDCNetPlus:
         confidence f32[P,H,W]).  Each frame is encoded once per chunk, and the backward flow needed by the
         confidence of (s, t) is shared with pair (t, s) when both are requested."""
         pairs = [(int(s), int(t)) for s, t in pairs]
+        H0, W0 = frames.shape[1], frames.shape[2]
         frames = self.network.pad_to_8(frames.contiguous())
+        # one executor call addresses its operands with 32-bit offsets: 113 pairs at 512x768 but 21 at 1920x1080
+        max_flows = max(1, min(int(max_flows), self.network.max_pairs(frames.shape[1], frames.shape[2])))
         need = {}                                    # directed flow (image1, image2) -> slot
         for s, t in pairs:
             need.setdefault((t, s), len(need))       # flow on t's grid into s
@@ -119,7 +126,7 @@ class PDCNetPlus:
         fw = torch.stack([flows[need[(t, s)]] for s, t in pairs])
         bw = torch.stack([flows[need[(s, t)]] for s, t in pairs])
         conf, _ = ops.fb_confidence(fw.contiguous(), bw.contiguous(), self.sigma)
-        return fw, conf
+        return _unpad(fw, H0, W0), _unpad(conf, H0, W0)
 
     # ---- reference-compatible host API ---------------------------------------------------------
     @torch.no_grad()
@@ -136,6 +143,16 @@ class PDCNetPlus:
         device; returns (flow_est, confidence) whose items assign into numpy slots (:598-599)."""
         flow, conf, _ = self.calc_batch_device(source.contiguous(), target.contiguous(), bgr=False)
         return flow.cpu().numpy(), conf.cpu().numpy()
+
+
+def _unpad(t: torch.Tensor, H: int, W: int) -> torch.Tensor:
+    """Undo `RaftEngine.pad_to_8` (InputPadder 'sintel': centred replicate padding, utils.py:9-16) on a [B,Hp,Wp(,C)]
+    tensor.  No-op (no copy) when nothing was padded."""
+    Hp, Wp = t.shape[1], t.shape[2]
+    if Hp == H and Wp == W:
+        return t
+    y0, x0 = (Hp - H) // 2, (Wp - W) // 2
+    return t[:, y0:y0 + H, x0:x0 + W].contiguous()
 
 
 def create_of_algo(ckpt, precision: str = "fp32") -> PDCNetPlus:

@@ -89,7 +89,9 @@ def load_checkpoint(ckpt) -> Dict[str, torch.Tensor]:
             raise FileNotFoundError(
                 f"flow checkpoint {ckpt!r} not found (pass a RAFT state_dict path such as raft-things.pth, "
                 "a state_dict, or 'random:<seed>')")
-        sd = torch.load(ckpt, map_location="cpu")
+        # a state_dict of tensors needs nothing but tensors: never unpickle arbitrary objects from a user-supplied
+        # path (OFX_UNSAFE_CHECKPOINT=1 opts back in for legacy .pth.tar files that pickle their args namespace)
+        sd = torch.load(ckpt, map_location="cpu", weights_only=os.environ.get("OFX_UNSAFE_CHECKPOINT") != "1")
         if isinstance(sd, dict) and "state_dict" in sd and isinstance(sd["state_dict"], dict):
             sd = sd["state_dict"]
     else:

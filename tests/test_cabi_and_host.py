@@ -126,3 +126,15 @@ def test_pad_to_8_matches_input_padder():
     ref, _ = RO.pad_to_8(img.permute(0, 3, 1, 2).float())
     assert tuple(got.shape) == (1, 40, 56, 3)
     assert torch.equal(got.permute(0, 3, 1, 2).float(), ref)
+
+
+def test_top_level_alt_cuda_corr_module_resolves():
+    """RAFT/core/corr.py:5-9 does `import alt_cuda_corr`: with the repository root on sys.path that import must give
+    the HIP-backed forward/backward (no compute here: no GPU)."""
+    import importlib
+    m = importlib.import_module("alt_cuda_corr")
+    from sd_animation_optical_flow_amd import alt_cuda_corr as inner
+    assert m.forward is inner.forward and m.backward is inner.backward
+    import torch
+    with pytest.raises(RuntimeError):
+        m.forward(torch.zeros(1, 4, 4, 8), torch.zeros(1, 4, 4, 8), torch.zeros(1, 1, 4, 4, 2), 1)   # CPU tensors

@@ -81,3 +81,39 @@ def test_two_rank_gloo_clip(tmp_path):
     assert torch.equal(warped, frames // 2 + 100)                                     # same result as one rank would give
     flow = torch.cat([p["flow"] for p in parts])
     assert torch.allclose(flow[..., 0], frames.float().mean(-1) + 11.0)
+
+
+# ------------------------------------------------------------------------------------------------
+# bench.py's own rank plumbing (self-launch, broadcast, barrier, MAX all-reduce, ONE JSON line)
+# ------------------------------------------------------------------------------------------------
+def _run_bench(argv, env_extra=None, timeout=240):
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    env.update(env_extra or {})
+    return subprocess.run([sys.executable, os.path.join(root, "bench.py")] + argv, capture_output=True, text=True,
+                          timeout=timeout, env=env, cwd=root)
+
+
+def test_bench_gpus2_self_launches_two_ranks_gloo():
+    """`python bench.py --gpus 2` with no launcher around it must start two ranks itself; with the hidden CPU stub
+    step (gloo) the whole dist path runs here: n_gpus and the collective library's own rank count both say 2."""
+    import json
+    r = _run_bench(["--gpus", "2", "--steps", "3", "--warmup", "1", "--stub-step"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.strip().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout                       # ONE JSON line, from rank 0 only
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["ranks_seen"] == 2 and out["steps"] == 3 and out["scaling"] == "weak"
+    assert out["value"] > 0 and out["ms_per_step"] >= 10.0  # the stub sleeps 10 ms per step
+
+
+def test_bench_refuses_to_measure_fewer_gpus_than_asked():
+    """No GPU here: `--gpus 2` must exit non-zero with a clear message instead of measuring one (or zero) devices."""
+    r = _run_bench(["--gpus", "2", "--steps", "1", "--warmup", "0"], env_extra={"HIP_VISIBLE_DEVICES": ""})
+    assert r.returncode != 0
+    assert "refusing" in r.stderr and "--gpus 2" in r.stderr
+    # a launcher that started a different number of ranks than --gpus names is refused as well
+    r = _run_bench(["--gpus", "4", "--stub-step"], env_extra={"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})
+    assert r.returncode != 0 and "WORLD_SIZE=1" in r.stderr

@@ -65,4 +65,11 @@ def test_mean_pixel_distance_and_generator_decisions(cuda):
     for th in (8.5, 30.0, 0.0):
         got = [(k, i) for _, k, i in keyframes.frame_generator(seq, fps=30.0, th=th, batch=3)]
         assert [k for k, _ in got] == KO.keyframe_flags(seq, fps=30.0, th=th) and [i for _, i in got] == list(range(len(seq)))
+    # keep_every = 3 (the reference's live setting): the gap that relaxes the threshold counts DROPPED frames too
+    # (ofgen_keyframe_inpaint.py:346-352), so a small max_gap makes the decisions depend on it
+    seq3 = [_scene(5, H, W, shift=s) for s in (0, 0, 0, 1, 1, 1, 3, 3, 3, 30, 30, 30, 31, 32, 33, 80)]
+    for th, mg in ((8.5, -1), (30.0, 12), (12.0, 10)):
+        got = [(k, i) for _, k, i in keyframes.frame_generator(seq3, fps=30.0, th=th, max_gap=mg, batch=2, keep_every=3)]
+        want = KO.keyframe_flags(seq3, fps=30.0, th=th, max_gap=mg, keep_every=3)
+        assert [k for k, _ in got] == want and [i for _, i in got] == list(range(len(want))) and len(want) == 6
     assert keyframes.gaps(24.0) == KO.gaps(24.0) == (8, 240) and keyframes.estimated_kernel_size(512, 768) == 7

@@ -506,3 +506,55 @@ def test_corr_volume_beyond_2gib_is_split_along_m(cuda):
     ref1 = torch.nn.functional.avg_pool2d(ref.view(len(rows), 1, h, w), 2)[:, 0]
     assert (pyr[1][rows] - ref1).abs().max().item() < 3e-5
     assert torch.isfinite(pyr[3]).all()
+
+
+def test_top_level_alt_cuda_corr_serves_an_alternate_corr_block_caller(cuda):
+    """`import alt_cuda_corr` (the module name RAFT/core/corr.py:5-9 imports) must resolve from the repository root
+    and serve a caller shaped like `AlternateCorrBlock.__call__` (corr.py:74-91): channels-last contiguous feature
+    maps, coords / 2^i as [B,1,H,W,2], `corr, = alt_cuda_corr.forward(f1, f2, coords, r)`, stack, reshape, / sqrt(dim).
+    The result must equal the all-pairs CorrBlock lookup (the equivalence that pins the CUDA original)."""
+    import alt_cuda_corr                                   # top-level, exactly the reference's import
+    import torch.nn.functional as F
+    from oracle import raft_oracle as RO
+    g = torch.Generator().manual_seed(5)
+    B, D, h, w, r, levels = 2, 64, 24, 32, 4, 4
+    fmap1 = torch.randn((B, D, h, w), generator=g)
+    fmap2 = torch.randn((B, D, h, w), generator=g)
+    coords = RO.coords_grid(B, h, w) + (torch.rand((B, 2, h, w), generator=g) - 0.5) * 9.0
+
+    def caller(fmap1, fmap2, coords):                      # the call pattern of corr.py:63-91, on the device
+        pyramid = [fmap2]
+        for _ in range(levels):
+            pyramid.append(F.avg_pool2d(pyramid[-1], 2, stride=2))
+        c = coords.permute(0, 2, 3, 1)
+        out = []
+        for i in range(levels):
+            f1 = fmap1.permute(0, 2, 3, 1).contiguous()
+            f2 = pyramid[i].permute(0, 2, 3, 1).contiguous()
+            ci = (c / 2 ** i).reshape(B, 1, h, w, 2).contiguous()
+            corr, = alt_cuda_corr.forward(f1, f2, ci, r)
+            out.append(corr.squeeze(1))
+        corr = torch.stack(out, dim=1).reshape(B, -1, h, w)
+        return corr / torch.sqrt(torch.tensor(float(D)))
+
+    got = caller(fmap1.cuda(), fmap2.cuda(), coords.cuda()).cpu()
+    ref = RO.corr_lookup(RO.corr_pyramid(fmap1, fmap2), coords)
+    assert tuple(got.shape) == (B, levels * 81, h, w)
+    assert (got - ref).abs().max().item() < 2e-4
+    with pytest.raises(RuntimeError):
+        alt_cuda_corr.forward(fmap1, fmap2, coords.reshape(B, 1, h, w, 2), r)          # CPU tensors: TORCH_CHECK
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two HIP devices")
+def test_cv2_tables_follow_the_device(cuda):
+    """The OpenCV interpolation tables live in device memory: one set per device, picked by the CURRENT device
+    (a process that moves its algorithm with `.to(other)` must not hand device 0's table pointers to device 1)."""
+    from sd_animation_optical_flow_amd import ops
+    g = torch.Generator().manual_seed(3)
+    fr = torch.randint(0, 256, (40, 56, 3), dtype=torch.uint8, generator=g)
+    fl = (torch.rand((1, 40, 56, 2), generator=g) - 0.5) * 7
+    outs = []
+    for d in (0, 1, 0):
+        with torch.cuda.device(d):
+            outs.append(ops.warp(fr.to(f"cuda:{d}"), fl.to(f"cuda:{d}"), mode="cv2_cubic").cpu())
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])

@@ -201,3 +201,86 @@ def test_small_grids_repeat_bit_for_bit(engine):
             ref = engine.forward(a, k, iters=it, serial=serial).clone()
             for _ in range(12):
                 assert torch.equal(engine.forward(a, k, iters=it, serial=serial), ref), (B, H, W, serial)
+
+
+# ------------------------------------------------------------------------------------------------
+# round 2: the benchmarked configuration itself, the reference's own vectors, and saturated gates
+# ------------------------------------------------------------------------------------------------
+def test_engine_against_the_reference_raft_vectors_directly(engine, raft_sd):
+    """One hop, no oracle in between: the HIP engine on the inputs of tests/golden/raft_ref_128x160.npz against the
+    outputs the REAL reference RAFT (RAFT/core/raft.py:86-144, imported by make_golden.py) produced for them."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "raft_ref_128x160.npz"))
+    i1 = torch.from_numpy(g["image1"]).permute(0, 2, 3, 1).contiguous().cuda()
+    i2 = torch.from_numpy(g["image2"]).permute(0, 2, 3, 1).contiguous().cuda()
+    up, lo = engine.forward(i1, i2, iters=20, want_low=True)
+    ref_up = torch.from_numpy(g["flow_up"]).permute(0, 2, 3, 1)
+    ref_lo = torch.from_numpy(g["flow_low"]).permute(0, 2, 3, 1)
+    assert _epe(up.cpu(), ref_up) < 1e-3
+    assert _epe(lo.cpu(), ref_lo) < 1e-3
+    assert (up.cpu() - ref_up).abs().max().item() < 1e-2
+    # stage vectors of the same file (stored in half precision: compare with a matching tolerance)
+    fm1 = engine.buffer("fmap1").cpu().reshape(1, 16, 20, 256).permute(0, 3, 1, 2)
+    ref_fm1 = torch.from_numpy(g["fmap1_f16"].astype(np.float32))
+    assert (fm1 - ref_fm1).abs().max().item() < 2e-3 * max(1.0, ref_fm1.abs().max().item())
+    p3 = engine.buffer("pyr3").cpu().reshape(-1)
+    assert (p3 - torch.from_numpy(g["pyr3"]).reshape(-1)).abs().max().item() < 5e-4
+
+
+def test_bench_workload_c3_b64_20iters_512x768(engine, raft_sd):
+    """BASELINE configs[2] exactly as bench.py times it: 64 frames of the synthetic clip against one shared key
+    frame, 20 iterations.  Frames {0, 31, 63} against the CPU oracle; every frame against its own single-pair
+    run (a pair's flow must not depend on the batch it rides in); warp + mask of the batch against their oracles
+    on those frames."""
+    import bench
+    from oracle import mask_oracle, warp_oracle
+    from sd_animation_optical_flow_amd import ops
+    B, H, W = 64, bench.H, bench.W
+    frames, key, key_ai, conf = bench.make_clip(B, H, W, torch.device("cuda"))
+    flow = engine.forward(frames, key, iters=bench.ITERS)
+    assert tuple(flow.shape) == (B, H, W, 2) and torch.isfinite(flow).all()
+    kf = key.cpu().permute(2, 0, 1)[None].float()
+    for b in (0, 31, 63):
+        _, up = RO.raft_forward(raft_sd, frames[b].cpu().permute(2, 0, 1)[None].float(), kf, iters=bench.ITERS)
+        e = _epe(flow[b].cpu(), up[0].permute(1, 2, 0))
+        assert e < 1e-3, (b, e)
+    worst = 0.0
+    for b in range(B):
+        single = engine.forward(frames[b:b + 1], key, iters=bench.ITERS)
+        worst = max(worst, (flow[b:b + 1] - single).abs().max().item())
+    assert worst < 2e-3, worst                         # 20 recurrent fp32 iterations, different tile schedules
+    warped, mask = ops.warp_and_mask(key_ai, flow, conf, warp_mode="bilinear", thres=0.95, ksize=7)
+    for b in (0, 31, 63):
+        ref_w = warp_oracle.warp_frame(key_ai.cpu().numpy(), flow[b].cpu().numpy(), mode="bilinear")
+        d = np.abs(warped[b].cpu().numpy().astype(np.int32) - ref_w.astype(np.int32))
+        assert d.max() <= 1 and (d > 0).mean() < 1e-3          # u8 rounding of an fp32 blend
+        c = conf[b].cpu().numpy()
+        ref_m, _ = mask_oracle.generate_mask(c, c.copy(), 0.95, 7)
+        assert np.array_equal(mask[b].cpu().numpy(), ref_m)
+
+
+def test_saturated_gates_stay_inside_the_bar(cuda, raft_sd):
+    """The GRU epilogues evaluate sigmoid / tanh with v_exp_f32 / v_rcp_f32 (ofx_internal.h) instead of libm.  A trained
+    checkpoint drives the gates into saturation far more than seeded weights do: scale the update block's gate and
+    motion-encoder weights x4 (and the context features with them) and hold the result to the same bar."""
+    from sd_animation_optical_flow_amd.raft import RaftEngine
+    sd = {k: v.clone() for k, v in raft_sd.items()}
+    for k in sd:
+        if k.startswith("update_block.gru.conv") or k.startswith("update_block.encoder.convc"):
+            sd[k] = sd[k] * 4.0
+    eng = RaftEngine(sd)
+    H, W, B = 128, 160, 2
+    key, frames = _frames(31, B, H, W)
+    img2 = key[None].repeat(B, 1, 1, 1)
+    tr = {}
+    lo_ref, up_ref = _oracle_flow(sd, frames, img2, 6, trace=tr)
+    up, lo = eng.forward(frames.cuda(), img2.cuda(), iters=6, want_low=True)
+    h, w = H // 8, W // 8
+    net_ref = tr["net_it0"]
+    sat = (net_ref.abs() > 0.999).float().mean().item()
+    hx = eng.buffer("hx").cpu().reshape(B * h * w, 384)
+    assert torch.isfinite(up).all()
+    assert _epe(up.cpu(), up_ref) < 1e-3, _epe(up.cpu(), up_ref)
+    assert (lo.cpu() - lo_ref).abs().max().item() < 5e-3
+    assert hx[:, :128].abs().max().item() <= 1.0 + 1e-6          # h is a convex mix of tanh values
+    print(f"saturated fraction of the hidden state after iteration 0: {sat:.3f}")

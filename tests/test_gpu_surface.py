@@ -245,3 +245,46 @@ def test_full_hd_frame_single_pair(cuda, raft_sd):
     ref = (f1[rows].double() @ f2.double().T / 16.0).float()
     got = eng.buffer("pyr0").view(N, N)[rows]
     assert (got - ref).abs().max().item() < 1e-4 * max(1.0, ref.abs().max().item())
+
+
+def test_calc_returns_the_unpadded_size_for_frames_not_divisible_by_8(algo, raft_sd):
+    """pdcnet_of.py:72-75 promises [H,W] outputs.  The network runs on the replicate-padded grid (InputPadder 'sintel',
+    utils.py:9-16); flow, confidence and log-confidence must be cropped back -- RAFT_2.calc alone keeps the padded size
+    (the reference never un-pads there)."""
+    f1, f2 = _pair(9, H=100, W=90)
+    flow, conf, logc = algo.calc(f1, f2)
+    assert flow.shape == (100, 90, 2) and conf.shape == (100, 90) and logc.shape == (100, 90)
+    ref = RO.raft2_calc(raft_sd, f2, f1)                     # padded: 104 x 96, offsets (2, 3)
+    assert ref.shape[:2] == (104, 96)
+    assert np.sqrt(((flow - ref[2:102, 3:93]) ** 2).sum(-1)).mean() < 1e-3
+    # warp / mask on the cropped outputs line up with the frame again
+    from sd_animation_optical_flow_amd import ofgen, pdcnet_of
+    assert pdcnet_of.warp_frame(f1, flow).shape == f1.shape
+    m, _ = ofgen.generate_mask(conf, logc.copy(), 0.95)
+    assert m.shape == (100, 90)
+    dev = torch.from_numpy(np.stack([f1, f2])).cuda()
+    fw, cf = algo.calc_pairs(dev, [(0, 1), (1, 0)], bgr=True)
+    assert tuple(fw.shape) == (2, 100, 90, 2) and tuple(cf.shape) == (2, 100, 90)
+    assert (fw[0].cpu().numpy() - flow).__abs__().max() < 1e-4
+
+
+def test_calc_pairs_honours_the_per_call_pair_limit(algo, monkeypatch):
+    """One executor call addresses its operands with 32-bit offsets (113 pairs at 512x768, 21 at 1080p): calc_pairs must
+    slice by RaftEngine.max_pairs, not by a fixed 64.  Mock the limit small and hold the result to the unsliced one."""
+    from sd_animation_optical_flow_amd.raft import RaftEngine
+    f1, f2 = _pair(10)
+    f3, _ = _pair(11)
+    dev = torch.from_numpy(np.stack([f1, f2, f3])).cuda()
+    pairs = [(s, t) for s in range(3) for t in range(3) if s != t]
+    want_f, want_c = algo.calc_pairs(dev, pairs)
+    calls = []
+    real = RaftEngine.forward_pairs
+
+    def spy(self, images, idx1, idx2, **kw):
+        calls.append(len(idx1))
+        return real(self, images, idx1, idx2, **kw)
+    monkeypatch.setattr(RaftEngine, "max_pairs", staticmethod(lambda H, W: 4))
+    monkeypatch.setattr(RaftEngine, "forward_pairs", spy)
+    got_f, got_c = algo.calc_pairs(dev, pairs)
+    assert calls and max(calls) <= 4 and sum(calls) == 6
+    assert (got_f - want_f).abs().max().item() < 1e-4 and (got_c - want_c).abs().max().item() < 1e-4
