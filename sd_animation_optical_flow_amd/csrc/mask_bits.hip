@@ -10,6 +10,8 @@
 // The byte-wise LDS kernel in warp_mask.hip remains the path for grey-value dilation (ofx_dilate_u8).
 #include "ofx_internal.h"
 
+#include <cstdlib>
+
 namespace {
 
 constexpr int kTW = 64;       // tile width  = one ballot
@@ -230,6 +232,175 @@ __global__ __launch_bounds__(256) void mask_bits_narrow_kernel(const BitArgs a) 
     }
 }
 
+
+// ---- full-row band variant (confidence sources, W % 4 == 0): the path of generate_mask on the hot path.
+// A workgroup owns kBH output rows of ONE image at full width.  Every confidence value is fetched with 16-byte
+// loads (a wavefront covers 256 pixels of a row per instruction; all of a wave's loads of a batch are in flight
+// before the first compare), a lane's 4 threshold bits are merged into 32-bit words with three DPP row shifts, and
+// the band's bitmap (+ r halo rows above and below, + one zero word either side of a row) lives in LDS: 70 bytes per
+// row at W = 512.  The elliptical dilation is then an OR of log-step "spreads" of 64-bit windows, and the result is
+// expanded to 0/255 bytes with 16-byte stores.  No horizontal halo exists (the row is whole), the vertical halo is
+// r rows per band edge, and workgroup ids are laid out so that the bands of an image share an XCD (its L2 serves
+// the halo rows).  Traffic: every confidence byte once from HBM, every mask byte once.
+constexpr int kBHMax = 64;              // output rows per band (runtime choice, <= kBHMax)
+
+template <int CTRL>
+__device__ __forceinline__ unsigned dpp_or(unsigned x) {
+    // x | (x of the lane CTRL-selected within the 16-lane row; 0 when that lane is outside the row)
+    return x | (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, CTRL, 0xF, 0xF, true);
+}
+
+// s[q] = OR_{e = 0..n-1} v[q + e]  (right spread) in O(log n) steps
+__device__ __forceinline__ unsigned long long spread_r(unsigned long long v, int n) {
+    int cover = 1;
+    while (cover < n) {
+        const int step = min(cover, n - cover);
+        v |= v >> step;
+        cover += step;
+    }
+    return v;
+}
+__device__ __forceinline__ unsigned long long spread_l(unsigned long long v, int n) {
+    int cover = 1;
+    while (cover < n) {
+        const int step = min(cover, n - cover);
+        v |= v << step;
+        cover += step;
+    }
+    return v;
+}
+
+__device__ __forceinline__ unsigned nibble_to_bytes(unsigned n) {   // 4 bits -> 4 bytes of 0x00 / 0xFF
+    return (((n & 0xFu) * 0x00204081u) & 0x01010101u) * 0xFFu;
+}
+
+// NT threads per workgroup, kRowBatch (row, chunk) loads in flight per wave, kBH output rows per band
+template <int SRC, int NT, int kRowBatch>
+__global__ __launch_bounds__(NT) void mask_rows_kernel(const BitArgs a, const int nbands, const int B, const int xcd_map,
+                                                       const int kBH) {
+    extern __shared__ unsigned lds[];
+    __shared__ signed char hw_s[2 * kMaxR + 2];
+    constexpr int NW = NT / 64;
+    const int W = a.W, H = a.H, r = a.r;
+    if (threadIdx.x < 2 * kMaxR + 1) hw_s[threadIdx.x] = a.hw[threadIdx.x];
+    const int nwords = (W + 31) >> 5;
+    const int rs = nwords + 2;                               // row stride in words: [0 | words | 0]
+    unsigned* in_bits = lds;                                 // (kBH + 2r) rows
+    unsigned* out_bits = lds + (kBHMax + 2 * kMaxR) * rs;    // kBH rows, nwords each
+    // ---- which band: bands of one image stay on one XCD when there are enough images to fill all eight
+    long img;
+    int band;
+    if (xcd_map) {
+        const int xcd = blockIdx.x & 7, k = blockIdx.x >> 3;
+        img = (long)(k / nbands) * 8 + xcd;
+        band = k % nbands;
+        if (img >= B) return;
+    } else {
+        img = blockIdx.x / nbands;
+        band = blockIdx.x % nbands;
+    }
+    const int y0 = band * kBH;
+    const int nrows = min(kBH, H - y0) + 2 * r;              // bitmap rows of this band
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // zero the pad words (and everything else once: rows outside the image stay 0)
+    for (int i = threadIdx.x; i < (kBH + 2 * r) * rs; i += NT) in_bits[i] = 0;
+    __syncthreads();
+    // ---- phase 1: threshold bits.  item = (row, chunk of 256 pixels); items are dealt round-robin to the waves
+    const int nchunks = (W + 255) >> 8;
+    const int nitems = nrows * nchunks;
+    const float* cbase = a.conf + img * (long)H * W;
+    float* lbase = a.log_conf ? a.log_conf + img * (long)H * W : nullptr;
+    for (int it0 = wave; it0 < nitems; it0 += NW * kRowBatch) {
+        float4 v[kRowBatch];
+        bool ok[kRowBatch];
+#pragma unroll
+        for (int u = 0; u < kRowBatch; ++u) {
+            const int it = it0 + NW * u;
+            const int row = it / nchunks, ch = it - row * nchunks;
+            const int y = y0 - r + row, x = (ch << 8) + (lane << 2);
+            ok[u] = it < nitems && (unsigned)y < (unsigned)H && x < W;
+            v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (ok[u]) v[u] = *reinterpret_cast<const float4*>(cbase + (long)y * W + x);
+        }
+#pragma unroll
+        for (int u = 0; u < kRowBatch; ++u) {
+            const int it = it0 + NW * u;
+            if (it >= nitems) break;                         // wave-uniform
+            const int row = it / nchunks, ch = it - row * nchunks;
+            unsigned n = 0;
+            if (ok[u]) {
+                if (SRC == OFX_MSRC_CONF_LT)
+                    n = (v[u].x < a.thres ? 1u : 0u) | (v[u].y < a.thres ? 2u : 0u) | (v[u].z < a.thres ? 4u : 0u) | (v[u].w < a.thres ? 8u : 0u);
+                else
+                    n = (!(v[u].x > a.thres) ? 1u : 0u) | (!(v[u].y > a.thres) ? 2u : 0u) | (!(v[u].z > a.thres) ? 4u : 0u) |
+                        (!(v[u].w > a.thres) ? 8u : 0u);
+                if (lbase != nullptr && n != 0 && row >= r && row < nrows - r) {
+                    // generate_mask's side effect on the band's own rows: log_confidence[low] = 0
+                    float* lp = lbase + (long)(y0 - r + row) * W + (ch << 8) + (lane << 2);
+                    if (n & 1u) lp[0] = 0.f;
+                    if (n & 2u) lp[1] = 0.f;
+                    if (n & 4u) lp[2] = 0.f;
+                    if (n & 8u) lp[3] = 0.f;
+                }
+            }
+            unsigned x32 = n << ((lane & 7) << 2);
+            x32 = dpp_or<0x111>(x32);                        // row_shr:1
+            x32 = dpp_or<0x112>(x32);                        // row_shr:2
+            x32 = dpp_or<0x114>(x32);                        // row_shr:4  -> lanes 7, 15, 23, ... hold 32 pixels each
+            const int word = (ch << 3) + (lane >> 3);
+            if ((lane & 7) == 7 && word < nwords) in_bits[row * rs + 1 + word] = x32;
+        }
+    }
+    __syncthreads();
+    // ---- phase 2: dilation, one 32-pixel word per item
+    const int orows = nrows - 2 * r;
+    for (int i = threadIdx.x; i < orows * nwords; i += NT) {
+        const int t = i / nwords, j = i - t * nwords;
+        unsigned acc = 0;
+        for (int dy = -r; dy <= r; ++dy) {
+            const int hw = hw_s[dy + r];
+            if (hw < 0) continue;
+            const unsigned* p = in_bits + (t + r + dy) * rs + 1 + j;
+            const unsigned left = p[-1], mid = p[0], right = p[1];
+            const unsigned long long w1 = (unsigned long long)left | ((unsigned long long)mid << 32);    // pixels 32(j-1) ..
+            const unsigned long long w2 = (unsigned long long)mid | ((unsigned long long)right << 32);   // pixels 32j ..
+            acc |= (unsigned)spread_r(w2, hw + 1) | (unsigned)(spread_l(w1, hw + 1) >> 32);
+        }
+        out_bits[t * nwords + j] = acc;
+    }
+    __syncthreads();
+    // ---- phase 3: bits -> bytes
+    uint8_t* obase = a.out + img * (long)H * W;
+    const uint8_t* orb = a.or_mask ? a.or_mask + img * (long)H * W : nullptr;
+    if ((W & 15) == 0) {
+        const int per_row = W >> 4;                          // 16-pixel groups
+        for (int i = threadIdx.x; i < orows * per_row; i += NT) {
+            const int t = i / per_row, g = i - t * per_row;
+            const unsigned bits = (out_bits[t * nwords + (g >> 1)] >> ((g & 1) << 4)) & 0xFFFFu;
+            uint4 o;
+            o.x = nibble_to_bytes(bits);
+            o.y = nibble_to_bytes(bits >> 4);
+            o.z = nibble_to_bytes(bits >> 8);
+            o.w = nibble_to_bytes(bits >> 12);
+            const long off = (long)(y0 + t) * W + (g << 4);
+            if (orb) {
+                const uint4 m = *reinterpret_cast<const uint4*>(orb + off);
+                o.x |= m.x; o.y |= m.y; o.z |= m.z; o.w |= m.w;
+            }
+            *reinterpret_cast<uint4*>(obase + off) = o;
+        }
+    } else {
+        const int per_row = W >> 2;                          // 4-pixel groups (W % 4 == 0)
+        for (int i = threadIdx.x; i < orows * per_row; i += NT) {
+            const int t = i / per_row, g = i - t * per_row;
+            unsigned o = nibble_to_bytes(out_bits[t * nwords + (g >> 3)] >> ((g & 7) << 2));
+            const long off = (long)(y0 + t) * W + (g << 2);
+            if (orb) o |= *reinterpret_cast<const unsigned*>(orb + off);
+            *reinterpret_cast<unsigned*>(obase + off) = o;
+        }
+    }
+}
+
 }  // namespace
 
 // hw[]: ellipse half width per row dy = -r..r (-1 = empty row); see make_ellipse in warp_mask.hip
@@ -242,6 +413,37 @@ int ofx_mask_bits_launch(int src, const float* conf, float* log_conf, const uint
     a.H = H; a.W = W; a.thres = thres; a.edge_thres = edge_thres; a.r = r;
     for (int i = 0; i < 2 * kMaxR + 1; ++i) a.hw[i] = i < 2 * r + 1 ? hw[i] : (signed char)-1;
     OfxProfScope prof(name, s);
+    if (src != OFX_MSRC_EDGES && (W & 3) == 0 && W <= 4096 && ofx_aligned16(conf) && ofx_aligned16(out) &&
+        (or_mask == nullptr || ofx_aligned16(or_mask))) {
+        // band height / workgroup shape: OFX_MASK_VARIANT (experiments) or the measured default
+        static const int variant = [] { const char* e = getenv("OFX_MASK_VARIANT"); return e ? atoi(e) : 0; }();
+        const int bh = (variant == 3 || variant == 4) ? 64 : 32;
+        const int nbands = ofx_cdiv(H, bh);
+        const int xcd_map = B >= 16 ? 1 : 0;
+        const long nwg = xcd_map ? (long)ofx_cdiv(B, 8) * 8 * nbands : (long)B * nbands;
+        OFX_REQUIRE(nwg < (1L << 31), OFX_EINVAL);
+        const int nwords = (W + 31) >> 5;
+        const size_t lds = ((size_t)(kBHMax + 2 * kMaxR) * (nwords + 2) + (size_t)kBHMax * nwords) * sizeof(unsigned);
+#define OFX_MASK_ROWS(NT, BATCH)                                                                                             \
+    do {                                                                                                                     \
+        if (src == OFX_MSRC_CONF_LT)                                                                                         \
+            hipLaunchKernelGGL((mask_rows_kernel<OFX_MSRC_CONF_LT, NT, BATCH>), dim3((unsigned)nwg), dim3(NT), lds, s, a, nbands, B, \
+                               xcd_map, bh);                                                                                 \
+        else                                                                                                                 \
+            hipLaunchKernelGGL((mask_rows_kernel<OFX_MSRC_CONF_NGT, NT, BATCH>), dim3((unsigned)nwg), dim3(NT), lds, s, a, nbands, B, \
+                               xcd_map, bh);                                                                                 \
+    } while (0)
+        switch (variant) {
+            case 1: OFX_MASK_ROWS(256, 10); break;
+            case 2: OFX_MASK_ROWS(512, 10); break;
+            case 3: OFX_MASK_ROWS(512, 9); break;
+            case 4: OFX_MASK_ROWS(1024, 9); break;
+            case 5: OFX_MASK_ROWS(256, 20); break;
+            default: OFX_MASK_ROWS(256, 8); break;
+        }
+#undef OFX_MASK_ROWS
+        return ofx_launch_status();
+    }
     if (r <= kNH) {
         dim3 gridn(ofx_cdiv(W, kNW), ofx_cdiv(H, kTH), B);
         switch (src) {

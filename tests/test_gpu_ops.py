@@ -558,3 +558,27 @@ def test_cv2_tables_follow_the_device(cuda):
         with torch.cuda.device(d):
             outs.append(ops.warp(fr.to(f"cuda:{d}"), fl.to(f"cuda:{d}"), mode="cv2_cubic").cpu())
     assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+
+
+@pytest.mark.parametrize("H,W,B", [(768, 512, 3), (70, 260, 2), (33, 4, 1), (64, 1028, 1), (200, 48, 17), (31, 2052, 2)])
+def test_generate_mask_band_kernel_shapes(cuda, H, W, B):
+    """The full-row band kernel (W % 4 == 0): widths that are / are not multiples of 16, 32 and 256, bands that end
+    mid-way, a batch large enough for the XCD-grouped workgroup order (B >= 16), every structuring element size class,
+    both comparison conventions and the in-place log-confidence reset -- all bit-exact against the oracle."""
+    ops = _ops()
+    rng = np.random.default_rng(H * 7 + W)
+    conf = rng.random((B, H, W)).astype(np.float32)
+    conf[:, ::5, ::3] = np.float32(0.9)                       # exactly-at-threshold values
+    conf[:, 0, :] = 0.0                                       # low first row / last column: border handling
+    conf[:, :, -1] = 0.0
+    for ksize, thres in ((7, 0.9), (1, 0.9), (3, 0.5), (15, 0.97), (31, 0.995)):
+        logc = np.log(conf + 1e-3).astype(np.float32)
+        lc = torch.from_numpy(logc.copy()).cuda()
+        out = ops.generate_mask(torch.from_numpy(conf).cuda(), lc, thres, ksize)
+        out2 = ops.generate_mask(torch.from_numpy(conf).cuda(), None, thres, ksize, cmp_gt=True)
+        for b in sorted({0, B - 1}):
+            ref_mask, ref_lc = MO.generate_mask(conf[b], logc[b].copy(), thres, ksize)
+            assert np.array_equal(out[b].cpu().numpy(), ref_mask), (ksize, b)
+            assert np.array_equal(lc[b].cpu().numpy(), ref_lc), (ksize, b)
+            ref2 = MO.dilate(np.where(conf[b] > np.float32(thres), 0, 255).astype(np.uint8), MO.ellipse_kernel(ksize))
+            assert np.array_equal(out2[b].cpu().numpy(), ref2), (ksize, b)
