@@ -50,6 +50,9 @@ enum { OFX_MSRC_CONF_LT = 0, OFX_MSRC_CONF_NGT = 1, OFX_MSRC_EDGES = 3 };   // c
 int ofx_mask_bits_launch(int src, const float* conf, float* log_conf, const uint8_t* image, const uint8_t* or_mask,
                          uint8_t* out, int B, int H, int W, float thres, int edge_thres, int r, const signed char* hw,
                          const char* name, hipStream_t s);
+// warp_fast.hip: bilinear warp of one shared uint8 RGB key frame (0 = launched, OFX_EINVAL = shape not taken)
+int ofx_warp_bilinear_shared_launch(const uint8_t* frame, const float* flow, uint8_t* out, int B, int H, int W, float sign,
+                                    hipStream_t s);
 int ofx_init_state(float* coords1, float* flow4, float* hx, int ldh, int flow_off, int B, int h, int w, hipStream_t s);
 int ofx_coords_to_flow(const float* coords1, float* flow, int B, int h, int w, hipStream_t s);
 int ofx_flow_head_launch(const float* x, int ldx, const float* w, int Kpad, const float* bias, float* coords1, float* hx_flow,

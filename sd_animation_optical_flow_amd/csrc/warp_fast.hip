@@ -1,0 +1,155 @@
+// Bilinear backward warp of ONE shared uint8 RGB key frame along B flow fields -- the warp of the hot path
+// (pdcnet_of.py:34-42 semantics in its `north_star` bilinear mode: out(y,x) = frame(y + fy, x + fx), zeros outside,
+// grid_sample(bilinear, zeros, align_corners=True) arithmetic; every frame of a shard warps the same AI key frame).
+//
+// The byte-triplet kernel in warp_mask.hip spends ~100 VALU instructions per pixel on border weights, unaligned
+// 3-byte taps and tap swaps and is VALU-bound at 3.2 TB/s.  Here the key frame is first expanded ONCE per call into a
+// zero-bordered RGBX image (4 bytes per pixel, 2 pixels of zeros all around; 1.6 MB at 512x768, stays in L2):
+//   * a tap row is one aligned 8-byte load (two RGBX pixels), no byte shuffling;
+//   * coordinates are clamped into the border with one v_med3 per axis -- out-of-image taps READ zeros, so there are
+//     no validity compares, no zeroed weights and no tap swaps;
+//   * blending is packed fp32 FMA; round-half-even + byte extraction is one add of 1.5 * 2^23 per channel and byte
+//     permutes (values are convex combinations of bytes: no clamp needed).
+// ~45 VALU instructions per pixel: the kernel moves its algorithmic bytes (8 B flow + 3 B out per pixel) at HBM rate.
+// This file is compiled with FMA contraction ON (u8 results may differ from the weights-form oracle by 1 LSB on
+// rounding ties only; the tests bound that).
+#include "ofx_internal.h"
+
+namespace {
+
+constexpr int kPad = 2;
+
+struct PadArgs {
+    const uint8_t* frame;     // [H][W][3]
+    uint32_t* pad;            // [(H + 4)][(W + 4)] RGBX
+    int H, W, Wp;
+    unsigned total;           // (H + 4) * (W + 4)
+};
+
+__global__ __launch_bounds__(256) void pad_rgbx_kernel(const PadArgs a) {
+    const unsigned i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= a.total) return;
+    const int yp = (int)(i / (unsigned)a.Wp), xp = (int)(i - (unsigned)yp * (unsigned)a.Wp);
+    const int y = yp - kPad, x = xp - kPad;
+    uint32_t v = 0;
+    if ((unsigned)y < (unsigned)a.H && (unsigned)x < (unsigned)a.W) {
+        const uint8_t* p = a.frame + ((size_t)y * a.W + x) * 3;
+        v = (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16);
+    }
+    a.pad[i] = v;
+}
+
+struct FastArgs {
+    const uint2* pad2;        // points at padded pixel (kPad, kPad); element = pixel pair starting at that pixel
+    const uint32_t* pad;      // same address, dword view
+    const float* flow;
+    uint8_t* out;
+    int H, W, W4, Wp;
+    unsigned ngroups;
+    unsigned magic_w4, magic_h;
+    float sign;
+};
+
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+
+__global__ __launch_bounds__(256) void warp_bilinear_shared_kernel(const FastArgs a) {
+    const unsigned g = blockIdx.x * 256u + threadIdx.x;
+    if (g >= a.ngroups) return;
+    const float4 fa = reinterpret_cast<const float4*>(a.flow)[2 * (size_t)g];
+    const float4 fb = reinterpret_cast<const float4*>(a.flow)[2 * (size_t)g + 1];
+    const unsigned row = a.W4 == 1 ? g : __umulhi(g, a.magic_w4);          // b*H + y
+    const int x = (int)(g - row * (unsigned)a.W4) * 4;
+    const unsigned b = a.H == 1 ? row : __umulhi(row, a.magic_h);
+    const int y = (int)(row - b * (unsigned)a.H);
+    const float xf = (float)x, yf = (float)y, Wf = (float)a.W, Hf = (float)a.H;
+    const float fxs[4] = {fa.x, fa.z, fb.x, fb.z}, fys[4] = {fa.y, fa.w, fb.y, fb.w};
+    uint2 top[4], bot[4];
+    float wx[4], wy[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        // (float)(x + j) + sign * f: the exact sum rounded once (the reference adds in f64 and casts)
+        const float mx = __builtin_fmaf(a.sign, fxs[j], xf + (float)j), my = __builtin_fmaf(a.sign, fys[j], yf);
+        const float x0f = __builtin_floorf(mx), y0f = __builtin_floorf(my);
+        wx[j] = mx - x0f;
+        wy[j] = my - y0f;
+        // clamp into the zero border in the float domain (one v_med3_f32 per axis; a NaN coordinate lands on the
+        // border too), then the conversion is exact
+        const int x0 = (int)__builtin_amdgcn_fmed3f(x0f, -(float)kPad, Wf), y0 = (int)__builtin_amdgcn_fmed3f(y0f, -(float)kPad, Hf);
+        const int idx = __mul24(y0, a.Wp) + x0;
+        top[j] = *reinterpret_cast<const uint2*>(a.pad + idx);
+        bot[j] = *reinterpret_cast<const uint2*>(a.pad + idx + a.Wp);
+    }
+    unsigned r[4][3];
+    const float kMagic = 12582912.0f;                                        // 1.5 * 2^23: (v + kMagic) holds rne(v) in its low byte
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float fx = wx[j], fy = wy[j], gx = 1.f - fx, gy = 1.f - fy;
+        const float w00 = gx * gy, w01 = fx * gy, w10 = gx * fy, w11 = fx * fy;
+        const unsigned p00 = top[j].x, p01 = top[j].y, p10 = bot[j].x, p11 = bot[j].y;
+        v2f acc = v2f{(float)(p00 & 0xFFu), (float)((p00 >> 8) & 0xFFu)} * w00;
+        float acc2 = (float)((p00 >> 16) & 0xFFu) * w00;
+        acc += v2f{(float)(p01 & 0xFFu), (float)((p01 >> 8) & 0xFFu)} * w01;
+        acc2 += (float)((p01 >> 16) & 0xFFu) * w01;
+        acc += v2f{(float)(p10 & 0xFFu), (float)((p10 >> 8) & 0xFFu)} * w10;
+        acc2 += (float)((p10 >> 16) & 0xFFu) * w10;
+        acc += v2f{(float)(p11 & 0xFFu), (float)((p11 >> 8) & 0xFFu)} * w11;
+        acc2 += (float)((p11 >> 16) & 0xFFu) * w11;
+        r[j][0] = __float_as_uint(acc.x + kMagic);
+        r[j][1] = __float_as_uint(acc.y + kMagic);
+        r[j][2] = __float_as_uint(acc2 + kMagic);
+    }
+    // byte 0 of each r -> 12 packed bytes.  __builtin_amdgcn_perm(hi, lo, sel): selector byte k picks byte (0-3 from lo,
+    // 4-7 from hi) for output byte k
+    auto pair = [](unsigned hi, unsigned lo) { return __builtin_amdgcn_perm(hi, lo, 0x0c0c0400u); };   // [lo.b0, hi.b0, 0, 0]
+    auto quad = [](unsigned hi2, unsigned lo2) { return __builtin_amdgcn_perm(hi2, lo2, 0x05040100u); }; // [lo2.b0, lo2.b1, hi2.b0, hi2.b1]
+    uint3 o;
+    o.x = quad(pair(r[1][0], r[0][2]), pair(r[0][1], r[0][0]));
+    o.y = quad(pair(r[2][1], r[2][0]), pair(r[1][2], r[1][1]));
+    o.z = quad(pair(r[3][2], r[3][1]), pair(r[3][0], r[2][2]));
+    const unsigned p0 = row * (unsigned)a.W + (unsigned)x;                   // first output pixel (p0 % 4 == 0)
+    *reinterpret_cast<uint3*>(a.out + (size_t)p0 * 3) = o;
+}
+
+}  // namespace
+
+// Returns 0 when the launch was taken, OFX_EINVAL when the shape is outside this path's limits (the caller then uses
+// the generic kernels), or a HIP error.  scratch: stream-ordered allocation of the padded key frame.
+int ofx_warp_bilinear_shared_launch(const uint8_t* frame, const float* flow, uint8_t* out, int B, int H, int W, float sign,
+                                    hipStream_t s) {
+    const long npix = (long)B * H * W;
+    if ((W & 3) != 0 || H < 1 || npix * 8 >= (1L << 32) || H + 2 * kPad >= (1 << 15) || W + 2 * kPad >= (1 << 15)) return OFX_EINVAL;
+    if ((((uintptr_t)flow) & 15u) != 0 || (((uintptr_t)out) & 3u) != 0) return OFX_EINVAL;
+    const int Wp = W + 2 * kPad, Hp = H + 2 * kPad;
+    const size_t pad_bytes = (size_t)Wp * Hp * sizeof(uint32_t);
+    uint32_t* pad = nullptr;
+    if (hipMallocAsync((void**)&pad, pad_bytes, s) != hipSuccess) {
+        (void)hipGetLastError();
+        return OFX_EINVAL;
+    }
+    PadArgs pa{frame, pad, H, W, Wp, (unsigned)(Wp * Hp)};
+    FastArgs a;
+    a.pad = pad + (size_t)kPad * Wp + kPad;
+    a.pad2 = nullptr;
+    a.flow = flow; a.out = out;
+    a.H = H; a.W = W; a.W4 = W >> 2; a.Wp = Wp;
+    a.ngroups = (unsigned)(npix >> 2);
+    auto magic = [](unsigned d) { return (unsigned)(((1ull << 32) + d - 1) / d); };   // umulhi(n, magic) == n / d for n * d < 2^32
+    a.magic_w4 = magic((unsigned)a.W4); a.magic_h = magic((unsigned)H);
+    a.sign = sign;
+    if (!((unsigned long long)a.ngroups * (unsigned)a.W4 < (1ull << 32) && (unsigned long long)B * H * (unsigned)H < (1ull << 32))) {
+        (void)hipFreeAsync(pad, s);
+        return OFX_EINVAL;
+    }
+    {
+        OfxProfScope prof("warp_pad_keyframe", s);
+        hipLaunchKernelGGL(pad_rgbx_kernel, dim3(ofx_cdiv(pa.total, 256)), dim3(256), 0, s, pa);
+    }
+    {
+        OfxProfScope prof("warp_u8", s);
+        hipLaunchKernelGGL(warp_bilinear_shared_kernel, dim3(ofx_cdiv(a.ngroups, 256)), dim3(256), 0, s, a);
+    }
+    int st = ofx_launch_status();
+    hipError_t e = hipFreeAsync(pad, s);
+    return st ? st : (int)e;
+}

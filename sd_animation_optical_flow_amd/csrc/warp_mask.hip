@@ -594,6 +594,11 @@ int launch_warp(const T* frame, long fbs, const float* flow, T* out, int B, int 
     }
     hipStream_t s = (hipStream_t)stream;
     const long npix = (long)B * H * W;
+    if (sizeof(T) == 1 && C == 3 && mode == OFX_WARP_BILINEAR && fbs == 0 && B >= 4) {
+        // one key frame shared by the batch (the hot path's case): zero-bordered RGBX staging + lean kernel (warp_fast.hip)
+        const int st = ofx_warp_bilinear_shared_launch((const uint8_t*)frame, flow, (uint8_t*)out, B, H, W, sign, s);
+        if (st != OFX_EINVAL) return st;
+    }
     if (sizeof(T) == 1 && C == 3 && mode == OFX_WARP_BILINEAR && (W & 3) == 0 && H >= 2 && npix * 8 < (1L << 32) &&
         (fbs == 0 || fbs == (long)H * W * 3) && (long)H * W * 3 >= 8 && (((uintptr_t)flow) & 15u) == 0 && (((uintptr_t)out) & 3u) == 0) {
         BilinArgs a;

@@ -582,3 +582,36 @@ def test_generate_mask_band_kernel_shapes(cuda, H, W, B):
             assert np.array_equal(lc[b].cpu().numpy(), ref_lc), (ksize, b)
             ref2 = MO.dilate(np.where(conf[b] > np.float32(thres), 0, 255).astype(np.uint8), MO.ellipse_kernel(ksize))
             assert np.array_equal(out2[b].cpu().numpy(), ref2), (ksize, b)
+
+
+@pytest.mark.parametrize("H,W,B", [(45, 36, 5), (64, 128, 4), (9, 4, 6), (768, 512, 4)])
+def test_warp_bilinear_shared_keyframe_fast_path(cuda, H, W, B):
+    """B >= 4 flows against ONE uint8 RGB key frame take the zero-bordered RGBX kernel (warp_fast.hip): borders, far
+    and non-finite flows, exact half-pixel ties, both flow conventions -- against the oracle (<= 1 LSB on rounding ties
+    only) and against the byte-triplet kernel that serves B < 4."""
+    ops = _ops()
+    rng = np.random.default_rng(H + W)
+    frame = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+    flows = (rng.standard_normal((B, H, W, 2)) * 4).astype(np.float32)
+    flows[0, 0, 1] = (-1.5, -0.5)                     # top-left border
+    flows[0, -1, -1] = (0.25, 0.25)                   # bottom-right: taps straddle the frame's last pixel
+    flows[1, H // 2, :] = (0.5, 0.5)                  # exact ties
+    flows[1, 0, :, 0] = -3.0                          # row 0 pointing left out of the image
+    flows[2] = flows[2] * 40                          # far flows: mostly outside
+    flows[3, 1, 1] = (1e30, -1e30)
+    flows[3, 2, 2] = (np.nan, 0.0)
+    fr, fl = torch.from_numpy(frame).cuda(), torch.from_numpy(flows).cuda()
+    for sign, conv in ((1.0, "pdcnet"), (-1.0, "raft")):
+        out = ops.warp(fr, fl, mode="bilinear", sign=sign).cpu().numpy()
+        assert out.shape == (B, H, W, 3)
+        for b in range(B if H < 100 else 2):
+            ref = WO.warp_frame(frame, np.nan_to_num(flows[b], nan=1e9), mode="bilinear", convention=conv)
+            d = np.abs(out[b].astype(int) - ref.astype(int))
+            if b == 3:
+                d[2, 2] = 0                           # NaN flow: any in-range byte is acceptable, no fault is the point
+            assert d.max() <= 1 and (d > 0).mean() < 2e-3, (b, d.max(), (d > 0).mean())
+            single = ops.warp(fr, fl[b:b + 1].contiguous(), mode="bilinear", sign=sign)[0].cpu().numpy()
+            d2 = np.abs(out[b].astype(int) - single.astype(int))
+            if b == 3:
+                d2[2, 2] = 0
+            assert d2.max() <= 1 and (d2 > 0).mean() < 2e-3
