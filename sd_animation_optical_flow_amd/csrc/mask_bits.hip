@@ -30,6 +30,11 @@ struct BitArgs {
     int edge_thres;
     int r;
     signed char hw[2 * kMaxR + 1];
+    // band kernel: the distinct half widths > 0 of the element ("planes", ascending) and, per element row, its plane
+    // (-1: empty row, -2: half width 0 = the raw bitmap); nplanes < 0: too many distinct widths, direct evaluation
+    signed char plane_hw[8];
+    signed char plane_of[2 * kMaxR + 1];
+    int nplanes;
 };
 
 __device__ __forceinline__ int reflect101(int i, int n) {
@@ -242,7 +247,6 @@ __global__ __launch_bounds__(256) void mask_bits_narrow_kernel(const BitArgs a) 
 // expanded to 0/255 bytes with 16-byte stores.  No horizontal halo exists (the row is whole), the vertical halo is
 // r rows per band edge, and workgroup ids are laid out so that the bands of an image share an XCD (its L2 serves
 // the halo rows).  Traffic: every confidence byte once from HBM, every mask byte once.
-constexpr int kBHMax = 64;              // output rows per band (runtime choice, <= kBHMax)
 
 template <int CTRL>
 __device__ __forceinline__ unsigned dpp_or(unsigned x) {
@@ -279,14 +283,19 @@ template <int SRC, int NT, int kRowBatch>
 __global__ __launch_bounds__(NT) void mask_rows_kernel(const BitArgs a, const int nbands, const int B, const int xcd_map,
                                                        const int kBH) {
     extern __shared__ unsigned lds[];
-    __shared__ signed char hw_s[2 * kMaxR + 2];
+    __shared__ signed char hw_s[2 * kMaxR + 2], plane_s[2 * kMaxR + 2], plane_hw_s[8];
     constexpr int NW = NT / 64;
     const int W = a.W, H = a.H, r = a.r;
-    if (threadIdx.x < 2 * kMaxR + 1) hw_s[threadIdx.x] = a.hw[threadIdx.x];
+    if (threadIdx.x < 2 * kMaxR + 1) {
+        hw_s[threadIdx.x] = a.hw[threadIdx.x];
+        plane_s[threadIdx.x] = a.plane_of[threadIdx.x];
+        if (threadIdx.x < 8) plane_hw_s[threadIdx.x] = a.plane_hw[threadIdx.x];
+    }
     const int nwords = (W + 31) >> 5;
     const int rs = nwords + 2;                               // row stride in words: [0 | words | 0]
     unsigned* in_bits = lds;                                 // (kBH + 2r) rows
-    unsigned* out_bits = lds + (kBHMax + 2 * kMaxR) * rs;    // kBH rows, nwords each
+    unsigned* out_bits = in_bits + (kBH + 2 * r) * rs;       // kBH rows, nwords each
+    unsigned* planes = out_bits + kBH * nwords;              // nplanes x (kBH + 2r) rows x nwords
     // ---- which band: bands of one image stay on one XCD when there are enough images to fill all eight
     long img;
     int band;
@@ -354,19 +363,51 @@ __global__ __launch_bounds__(NT) void mask_rows_kernel(const BitArgs a, const in
     __syncthreads();
     // ---- phase 2: dilation, one 32-pixel word per item
     const int orows = nrows - 2 * r;
-    for (int i = threadIdx.x; i < orows * nwords; i += NT) {
-        const int t = i / nwords, j = i - t * nwords;
-        unsigned acc = 0;
-        for (int dy = -r; dy <= r; ++dy) {
-            const int hw = hw_s[dy + r];
-            if (hw < 0) continue;
-            const unsigned* p = in_bits + (t + r + dy) * rs + 1 + j;
+    if (a.nplanes >= 0) {
+        // (a) per bitmap row, the horizontal spread for every distinct half width of the element (incremental: the
+        //     spread for width k extends the one for k - 1 by one funnel shift either side) ...
+        const int np = a.nplanes;
+        const int pstride = (kBH + 2 * r) * nwords;
+        for (int i = threadIdx.x; i < nrows * nwords; i += NT) {
+            const int row = i / nwords, j = i - row * nwords;
+            const unsigned* p = in_bits + row * rs + 1 + j;
             const unsigned left = p[-1], mid = p[0], right = p[1];
-            const unsigned long long w1 = (unsigned long long)left | ((unsigned long long)mid << 32);    // pixels 32(j-1) ..
-            const unsigned long long w2 = (unsigned long long)mid | ((unsigned long long)right << 32);   // pixels 32j ..
-            acc |= (unsigned)spread_r(w2, hw + 1) | (unsigned)(spread_l(w1, hw + 1) >> 32);
+            unsigned acc = mid;
+            int e = 1;
+            for (int k = 0; k < np; ++k) {
+                const int hw = plane_hw_s[k];
+                for (; e <= hw; ++e)
+                    acc |= __builtin_amdgcn_alignbit(right, mid, e) | __builtin_amdgcn_alignbit(mid, left, 32 - e);
+                planes[k * pstride + i] = acc;
+            }
         }
-        out_bits[t * nwords + j] = acc;
+        __syncthreads();
+        // (b) ... then the vertical OR over the element's rows
+        for (int i = threadIdx.x; i < orows * nwords; i += NT) {
+            const int t = i / nwords, j = i - t * nwords;
+            unsigned acc = 0;
+            for (int dy = -r; dy <= r; ++dy) {
+                const int pl = plane_s[dy + r];
+                if (pl == -1) continue;
+                acc |= pl == -2 ? in_bits[(t + r + dy) * rs + 1 + j] : planes[pl * pstride + (t + r + dy) * nwords + j];
+            }
+            out_bits[i] = acc;
+        }
+    } else {
+        for (int i = threadIdx.x; i < orows * nwords; i += NT) {
+            const int t = i / nwords, j = i - t * nwords;
+            unsigned acc = 0;
+            for (int dy = -r; dy <= r; ++dy) {
+                const int hw = hw_s[dy + r];
+                if (hw < 0) continue;
+                const unsigned* p = in_bits + (t + r + dy) * rs + 1 + j;
+                const unsigned left = p[-1], mid = p[0], right = p[1];
+                const unsigned long long w1 = (unsigned long long)left | ((unsigned long long)mid << 32);    // pixels 32(j-1) ..
+                const unsigned long long w2 = (unsigned long long)mid | ((unsigned long long)right << 32);   // pixels 32j ..
+                acc |= (unsigned)spread_r(w2, hw + 1) | (unsigned)(spread_l(w1, hw + 1) >> 32);
+            }
+            out_bits[i] = acc;
+        }
     }
     __syncthreads();
     // ---- phase 3: bits -> bytes
@@ -423,7 +464,25 @@ int ofx_mask_bits_launch(int src, const float* conf, float* log_conf, const uint
         const long nwg = xcd_map ? (long)ofx_cdiv(B, 8) * 8 * nbands : (long)B * nbands;
         OFX_REQUIRE(nwg < (1L << 31), OFX_EINVAL);
         const int nwords = (W + 31) >> 5;
-        const size_t lds = ((size_t)(kBHMax + 2 * kMaxR) * (nwords + 2) + (size_t)kBHMax * nwords) * sizeof(unsigned);
+        // distinct half widths of the element -> planes
+        a.nplanes = 0;
+        for (int hwv = 1; hwv <= kMaxR && a.nplanes >= 0; ++hwv) {
+            bool used = false;
+            for (int i = 0; i < 2 * r + 1; ++i) used |= a.hw[i] == hwv;
+            if (!used) continue;
+            if (a.nplanes == 8) { a.nplanes = -1; break; }
+            a.plane_hw[a.nplanes++] = (signed char)hwv;
+        }
+        for (int i = 0; i < 2 * kMaxR + 1; ++i) {
+            a.plane_of[i] = -1;
+            if (i < 2 * r + 1 && a.hw[i] == 0) a.plane_of[i] = -2;
+            for (int k = 0; k < a.nplanes; ++k)
+                if (i < 2 * r + 1 && a.hw[i] == a.plane_hw[k]) a.plane_of[i] = (signed char)k;
+        }
+        auto lds_words = [&](int np) { return (size_t)(bh + 2 * r) * (nwords + 2) + (size_t)bh * nwords + (size_t)np * (bh + 2 * r) * nwords; };
+        if (a.nplanes > 0 && lds_words(a.nplanes) * sizeof(unsigned) > 48 * 1024) a.nplanes = -1;   // wide frames x many widths: direct
+        const size_t lds = lds_words(a.nplanes > 0 ? a.nplanes : 0) * sizeof(unsigned);
+        OFX_REQUIRE(lds <= 64 * 1024, OFX_EINVAL);
 #define OFX_MASK_ROWS(NT, BATCH)                                                                                             \
     do {                                                                                                                     \
         if (src == OFX_MSRC_CONF_LT)                                                                                         \

@@ -15,6 +15,9 @@
 // rounding ties only; the tests bound that).
 #include "ofx_internal.h"
 
+#include <algorithm>
+#include <cstdlib>
+
 namespace {
 
 constexpr int kPad = 2;
@@ -53,11 +56,7 @@ struct FastArgs {
 typedef float v2f __attribute__((ext_vector_type(2)));
 
 
-__global__ __launch_bounds__(256) void warp_bilinear_shared_kernel(const FastArgs a) {
-    const unsigned g = blockIdx.x * 256u + threadIdx.x;
-    if (g >= a.ngroups) return;
-    const float4 fa = reinterpret_cast<const float4*>(a.flow)[2 * (size_t)g];
-    const float4 fb = reinterpret_cast<const float4*>(a.flow)[2 * (size_t)g + 1];
+__device__ __forceinline__ void warp_group(const FastArgs& a, const unsigned g, const float4 fa, const float4 fb) {
     const unsigned row = a.W4 == 1 ? g : __umulhi(g, a.magic_w4);          // b*H + y
     const int x = (int)(g - row * (unsigned)a.W4) * 4;
     const unsigned b = a.H == 1 ? row : __umulhi(row, a.magic_h);
@@ -111,6 +110,37 @@ __global__ __launch_bounds__(256) void warp_bilinear_shared_kernel(const FastArg
     *reinterpret_cast<uint3*>(a.out + (size_t)p0 * 3) = o;
 }
 
+// one group of 4 pixels per thread
+__global__ __launch_bounds__(256) void warp_bilinear_shared_kernel(const FastArgs a) {
+    const unsigned g = blockIdx.x * 256u + threadIdx.x;
+    if (g >= a.ngroups) return;
+    const float4 fa = reinterpret_cast<const float4*>(a.flow)[2 * (size_t)g];
+    const float4 fb = reinterpret_cast<const float4*>(a.flow)[2 * (size_t)g + 1];
+    warp_group(a, g, fa, fb);
+}
+
+// grid-stride variant: the flow of the NEXT group is already in flight while the current one gathers and blends (a
+// thread's HBM request then overlaps its own dependent L2 gathers instead of only those of other wavefronts)
+__global__ __launch_bounds__(256) void warp_bilinear_shared_loop_kernel(const FastArgs a) {
+    unsigned g = blockIdx.x * 256u + threadIdx.x;
+    const unsigned stride = gridDim.x * 256u;
+    if (g >= a.ngroups) return;
+    float4 fa = reinterpret_cast<const float4*>(a.flow)[2 * (size_t)g];
+    float4 fb = reinterpret_cast<const float4*>(a.flow)[2 * (size_t)g + 1];
+    for (;;) {
+        const unsigned gn = g + stride;
+        const bool more = gn < a.ngroups;
+        float4 na = fa, nb = fb;
+        if (more) {
+            na = reinterpret_cast<const float4*>(a.flow)[2 * (size_t)gn];
+            nb = reinterpret_cast<const float4*>(a.flow)[2 * (size_t)gn + 1];
+        }
+        warp_group(a, g, fa, fb);
+        if (!more) break;
+        g = gn; fa = na; fb = nb;
+    }
+}
+
 }  // namespace
 
 // Returns 0 when the launch was taken, OFX_EINVAL when the shape is outside this path's limits (the caller then uses
@@ -146,8 +176,13 @@ int ofx_warp_bilinear_shared_launch(const uint8_t* frame, const float* flow, uin
         hipLaunchKernelGGL(pad_rgbx_kernel, dim3(ofx_cdiv(pa.total, 256)), dim3(256), 0, s, pa);
     }
     {
+        static const int variant = [] { const char* e = getenv("OFX_WARP_VARIANT"); return e ? atoi(e) : 0; }();
         OfxProfScope prof("warp_u8", s);
-        hipLaunchKernelGGL(warp_bilinear_shared_kernel, dim3(ofx_cdiv(a.ngroups, 256)), dim3(256), 0, s, a);
+        const int full = ofx_cdiv(a.ngroups, 256);
+        if (variant >= 1)     // resident grid: 256 CUs x (8 / 6 / 4 workgroups)
+            hipLaunchKernelGGL(warp_bilinear_shared_loop_kernel, dim3(std::min(full, 256 * (variant == 1 ? 8 : variant == 2 ? 6 : 16))), dim3(256), 0, s, a);
+        else
+            hipLaunchKernelGGL(warp_bilinear_shared_kernel, dim3(full), dim3(256), 0, s, a);
     }
     int st = ofx_launch_status();
     hipError_t e = hipFreeAsync(pad, s);
