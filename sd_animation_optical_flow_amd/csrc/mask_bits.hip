@@ -10,7 +10,6 @@
 // The byte-wise LDS kernel in warp_mask.hip remains the path for grey-value dilation (ofx_dilate_u8).
 #include "ofx_internal.h"
 
-#include <cstdlib>
 
 namespace {
 
@@ -246,7 +245,10 @@ __global__ __launch_bounds__(256) void mask_bits_narrow_kernel(const BitArgs a) 
 // row at W = 512.  The elliptical dilation is then an OR of log-step "spreads" of 64-bit windows, and the result is
 // expanded to 0/255 bytes with 16-byte stores.  No horizontal halo exists (the row is whole), the vertical halo is
 // r rows per band edge, and workgroup ids are laid out so that the bands of an image share an XCD (its L2 serves
-// the halo rows).  Traffic: every confidence byte once from HBM, every mask byte once.
+// the halo rows).  Measured, B = 64 x 512x768 (tools/mask_bench.py): 7x7 27 us = 4.6 TB/s of algorithmic bytes (the
+// 56-column tile kernel above: 69 us); 1x1 (no halo, no dilation) 21.5 us = 5.9 TB/s is this access pattern's floor
+// (the 4:1 read:write mix of a float-in / byte-out kernel; a 1 GiB float4 read alone runs at 6.4 TB/s here, a write at
+// 4.4).  PMC FETCH_SIZE says the halo rows are re-fetched past L2 (7x7: +9 % reads at 64-row bands).
 
 template <int CTRL>
 __device__ __forceinline__ unsigned dpp_or(unsigned x) {
@@ -456,14 +458,17 @@ int ofx_mask_bits_launch(int src, const float* conf, float* log_conf, const uint
     OfxProfScope prof(name, s);
     if (src != OFX_MSRC_EDGES && (W & 3) == 0 && W <= 4096 && ofx_aligned16(conf) && ofx_aligned16(out) &&
         (or_mask == nullptr || ofx_aligned16(or_mask))) {
-        // band height / workgroup shape: OFX_MASK_VARIANT (experiments) or the measured default
-        static const int variant = [] { const char* e = getenv("OFX_MASK_VARIANT"); return e ? atoi(e) : 0; }();
-        const int bh = (variant == 3 || variant == 4) ? 64 : 32;
+        // band height / workgroup shape, measured at B = 64, 512x768, 7x7 (tools/mask_bench.py): 64 rows x 512 threads
+        // 26.7-27.5 us, 32 x 256: 28.1-29.4, 96 x 512: 28.4, 16 x 256: 29.9, 64 x 1024: 32.4 (the vertical halo is 2r
+        // rows per band, so taller bands re-read less); small batches take shorter bands to keep every CU busy
+        const int nwords = (W + 31) >> 5;
+        int bh = 64;
+        if ((long)B * ofx_cdiv(H, 64) < 512) bh = 32;
+        if ((long)B * ofx_cdiv(H, 32) < 512) bh = 16;
         const int nbands = ofx_cdiv(H, bh);
         const int xcd_map = B >= 16 ? 1 : 0;
         const long nwg = xcd_map ? (long)ofx_cdiv(B, 8) * 8 * nbands : (long)B * nbands;
         OFX_REQUIRE(nwg < (1L << 31), OFX_EINVAL);
-        const int nwords = (W + 31) >> 5;
         // distinct half widths of the element -> planes
         a.nplanes = 0;
         for (int hwv = 1; hwv <= kMaxR && a.nplanes >= 0; ++hwv) {
@@ -492,14 +497,10 @@ int ofx_mask_bits_launch(int src, const float* conf, float* log_conf, const uint
             hipLaunchKernelGGL((mask_rows_kernel<OFX_MSRC_CONF_NGT, NT, BATCH>), dim3((unsigned)nwg), dim3(NT), lds, s, a, nbands, B, \
                                xcd_map, bh);                                                                                 \
     } while (0)
-        switch (variant) {
-            case 1: OFX_MASK_ROWS(256, 10); break;
-            case 2: OFX_MASK_ROWS(512, 10); break;
-            case 3: OFX_MASK_ROWS(512, 9); break;
-            case 4: OFX_MASK_ROWS(1024, 9); break;
-            case 5: OFX_MASK_ROWS(256, 20); break;
-            default: OFX_MASK_ROWS(256, 8); break;
-        }
+        if (bh == 64)
+            OFX_MASK_ROWS(512, 9);
+        else
+            OFX_MASK_ROWS(256, 8);
 #undef OFX_MASK_ROWS
         return ofx_launch_status();
     }

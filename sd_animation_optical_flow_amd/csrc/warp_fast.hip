@@ -10,13 +10,17 @@
 //     no validity compares, no zeroed weights and no tap swaps;
 //   * blending is packed fp32 FMA; round-half-even + byte extraction is one add of 1.5 * 2^23 per channel and byte
 //     permutes (values are convex combinations of bytes: no clamp needed).
-// ~45 VALU instructions per pixel: the kernel moves its algorithmic bytes (8 B flow + 3 B out per pixel) at HBM rate.
+// ~50 VALU instructions per pixel (was ~100).  A workgroup covers a 64 x 16 pixel tile so that the source rows its taps
+// touch are shared inside one CU's L1.  Measured (B = 64, 512x768, tools/warp_bench.py): 64-69 us = 4.0-4.3 TB/s of
+// algorithmic bytes against 85 us before.  What bounds it now (DESIGN.md has the table): removing any ONE of the three
+// memory streams -- flow loads, taps, stores -- gives 46-48 us (the rate of the stream pair that remains), while
+// restructurings that keep all three (row-pair taps in one 16-byte load, LDS-staged taps per workgroup or per
+// wavefront, lane-contiguous taps, software-pipelined grid-stride loops, 8 pixels per thread, dense 16-byte stores,
+// non-temporal flow loads) all measured 69-117 us: the three dependent round trips of a wavefront through one CU's
+// in-order vector-memory path add up, and HBM writes (4.4 TB/s peak here vs 6.4 TB/s for reads) share the channel.
 // This file is compiled with FMA contraction ON (u8 results may differ from the weights-form oracle by 1 LSB on
 // rounding ties only; the tests bound that).
 #include "ofx_internal.h"
-
-#include <algorithm>
-#include <cstdlib>
 
 namespace {
 
@@ -43,24 +47,18 @@ __global__ __launch_bounds__(256) void pad_rgbx_kernel(const PadArgs a) {
 }
 
 struct FastArgs {
-    const uint2* pad2;        // points at padded pixel (kPad, kPad); element = pixel pair starting at that pixel
-    const uint32_t* pad;      // same address, dword view
+    const uint32_t* pad;      // points at padded pixel (kPad, kPad)
     const float* flow;
     uint8_t* out;
-    int H, W, W4, Wp;
-    unsigned ngroups;
-    unsigned magic_w4, magic_h;
+    int H, W, Wp;
     float sign;
 };
 
 typedef float v2f __attribute__((ext_vector_type(2)));
 
-
-__device__ __forceinline__ void warp_group(const FastArgs& a, const unsigned g, const float4 fa, const float4 fb) {
-    const unsigned row = a.W4 == 1 ? g : __umulhi(g, a.magic_w4);          // b*H + y
-    const int x = (int)(g - row * (unsigned)a.W4) * 4;
-    const unsigned b = a.H == 1 ? row : __umulhi(row, a.magic_h);
-    const int y = (int)(row - b * (unsigned)a.H);
+// 4 consecutive output pixels per thread; x % 4 == 0; row = b * H + y
+__device__ __forceinline__ void warp_group(const FastArgs& a, const unsigned row, const int x, const int y, const float4 fa,
+                                           const float4 fb) {
     const float xf = (float)x, yf = (float)y, Wf = (float)a.W, Hf = (float)a.H;
     const float fxs[4] = {fa.x, fa.z, fb.x, fb.z}, fys[4] = {fa.y, fa.w, fb.y, fb.w};
     uint2 top[4], bot[4];
@@ -106,51 +104,40 @@ __device__ __forceinline__ void warp_group(const FastArgs& a, const unsigned g, 
     o.x = quad(pair(r[1][0], r[0][2]), pair(r[0][1], r[0][0]));
     o.y = quad(pair(r[2][1], r[2][0]), pair(r[1][2], r[1][1]));
     o.z = quad(pair(r[3][2], r[3][1]), pair(r[3][0], r[2][2]));
-    const unsigned p0 = row * (unsigned)a.W + (unsigned)x;                   // first output pixel (p0 % 4 == 0)
-    *reinterpret_cast<uint3*>(a.out + (size_t)p0 * 3) = o;
+    *reinterpret_cast<uint3*>(a.out + ((size_t)row * a.W + x) * 3) = o;      // (row * W + x) % 4 == 0: 4-byte aligned
 }
 
-// one group of 4 pixels per thread
-__global__ __launch_bounds__(256) void warp_bilinear_shared_kernel(const FastArgs a) {
-    const unsigned g = blockIdx.x * 256u + threadIdx.x;
-    if (g >= a.ngroups) return;
-    const float4 fa = reinterpret_cast<const float4*>(a.flow)[2 * (size_t)g];
-    const float4 fb = reinterpret_cast<const float4*>(a.flow)[2 * (size_t)g + 1];
-    warp_group(a, g, fa, fb);
-}
+constexpr int kTileW = 64, kTileH = 16;
 
-// grid-stride variant: the flow of the NEXT group is already in flight while the current one gathers and blends (a
-// thread's HBM request then overlaps its own dependent L2 gathers instead of only those of other wavefronts)
-__global__ __launch_bounds__(256) void warp_bilinear_shared_loop_kernel(const FastArgs a) {
-    unsigned g = blockIdx.x * 256u + threadIdx.x;
-    const unsigned stride = gridDim.x * 256u;
-    if (g >= a.ngroups) return;
-    float4 fa = reinterpret_cast<const float4*>(a.flow)[2 * (size_t)g];
-    float4 fb = reinterpret_cast<const float4*>(a.flow)[2 * (size_t)g + 1];
-    for (;;) {
-        const unsigned gn = g + stride;
-        const bool more = gn < a.ngroups;
-        float4 na = fa, nb = fb;
-        if (more) {
-            na = reinterpret_cast<const float4*>(a.flow)[2 * (size_t)gn];
-            nb = reinterpret_cast<const float4*>(a.flow)[2 * (size_t)gn + 1];
-        }
-        warp_group(a, g, fa, fb);
-        if (!more) break;
-        g = gn; fa = na; fb = nb;
-    }
+__global__ __launch_bounds__(256) void warp_bilinear_shared_kernel(const FastArgs a, const int tiles_x, const int tiles_y) {
+    const int txi = blockIdx.x % tiles_x;
+    const int rest = blockIdx.x / tiles_x;
+    const int tyi = rest % tiles_y;
+    const int b = rest / tiles_y;
+    const int x = txi * kTileW + ((threadIdx.x & 15) << 2), y = tyi * kTileH + (threadIdx.x >> 4);
+    if (x >= a.W || y >= a.H) return;                        // W % 4 == 0: a group of 4 is inside or outside as a whole
+    const unsigned row = (unsigned)b * (unsigned)a.H + (unsigned)y;
+    const size_t p0 = (size_t)row * a.W + x;
+    const float4 fa = reinterpret_cast<const float4*>(a.flow)[p0 >> 1];
+    const float4 fb = reinterpret_cast<const float4*>(a.flow)[(p0 >> 1) + 1];
+    warp_group(a, row, x, y, fa, fb);
 }
 
 }  // namespace
 
 // Returns 0 when the launch was taken, OFX_EINVAL when the shape is outside this path's limits (the caller then uses
-// the generic kernels), or a HIP error.  scratch: stream-ordered allocation of the padded key frame.
+// the generic kernels), or a HIP error.  The padded key frame is a stream-ordered allocation (hipMallocAsync /
+// hipFreeAsync on the caller's stream: no cross-stream sharing, nothing to synchronise).
 int ofx_warp_bilinear_shared_launch(const uint8_t* frame, const float* flow, uint8_t* out, int B, int H, int W, float sign,
                                     hipStream_t s) {
     const long npix = (long)B * H * W;
-    if ((W & 3) != 0 || H < 1 || npix * 8 >= (1L << 32) || H + 2 * kPad >= (1 << 15) || W + 2 * kPad >= (1 << 15)) return OFX_EINVAL;
+    if ((W & 3) != 0 || H < 1 || npix * 3 >= (1L << 40) || H + 2 * kPad >= (1 << 15) || W + 2 * kPad >= (1 << 15)) return OFX_EINVAL;
+    if ((long)B * H >= (1L << 31)) return OFX_EINVAL;
     if ((((uintptr_t)flow) & 15u) != 0 || (((uintptr_t)out) & 3u) != 0) return OFX_EINVAL;
     const int Wp = W + 2 * kPad, Hp = H + 2 * kPad;
+    const int tiles_x = ofx_cdiv(W, kTileW), tiles_y = ofx_cdiv(H, kTileH);
+    const long nwg = (long)tiles_x * tiles_y * B;
+    if (nwg >= (1L << 31)) return OFX_EINVAL;
     const size_t pad_bytes = (size_t)Wp * Hp * sizeof(uint32_t);
     uint32_t* pad = nullptr;
     if (hipMallocAsync((void**)&pad, pad_bytes, s) != hipSuccess) {
@@ -160,29 +147,16 @@ int ofx_warp_bilinear_shared_launch(const uint8_t* frame, const float* flow, uin
     PadArgs pa{frame, pad, H, W, Wp, (unsigned)(Wp * Hp)};
     FastArgs a;
     a.pad = pad + (size_t)kPad * Wp + kPad;
-    a.pad2 = nullptr;
     a.flow = flow; a.out = out;
-    a.H = H; a.W = W; a.W4 = W >> 2; a.Wp = Wp;
-    a.ngroups = (unsigned)(npix >> 2);
-    auto magic = [](unsigned d) { return (unsigned)(((1ull << 32) + d - 1) / d); };   // umulhi(n, magic) == n / d for n * d < 2^32
-    a.magic_w4 = magic((unsigned)a.W4); a.magic_h = magic((unsigned)H);
+    a.H = H; a.W = W; a.Wp = Wp;
     a.sign = sign;
-    if (!((unsigned long long)a.ngroups * (unsigned)a.W4 < (1ull << 32) && (unsigned long long)B * H * (unsigned)H < (1ull << 32))) {
-        (void)hipFreeAsync(pad, s);
-        return OFX_EINVAL;
-    }
     {
         OfxProfScope prof("warp_pad_keyframe", s);
         hipLaunchKernelGGL(pad_rgbx_kernel, dim3(ofx_cdiv(pa.total, 256)), dim3(256), 0, s, pa);
     }
     {
-        static const int variant = [] { const char* e = getenv("OFX_WARP_VARIANT"); return e ? atoi(e) : 0; }();
         OfxProfScope prof("warp_u8", s);
-        const int full = ofx_cdiv(a.ngroups, 256);
-        if (variant >= 1)     // resident grid: 256 CUs x (8 / 6 / 4 workgroups)
-            hipLaunchKernelGGL(warp_bilinear_shared_loop_kernel, dim3(std::min(full, 256 * (variant == 1 ? 8 : variant == 2 ? 6 : 16))), dim3(256), 0, s, a);
-        else
-            hipLaunchKernelGGL(warp_bilinear_shared_kernel, dim3(full), dim3(256), 0, s, a);
+        hipLaunchKernelGGL(warp_bilinear_shared_kernel, dim3((unsigned)nwg), dim3(256), 0, s, a, tiles_x, tiles_y);
     }
     int st = ofx_launch_status();
     hipError_t e = hipFreeAsync(pad, s);
