@@ -190,7 +190,7 @@ def compose_warp_and_mask(flow_mat: np.ndarray, ai_frames: Sequence[np.ndarray],
 
 
 # --------------------------------------------------------------------------------------------------
-# PDCNetAux: batched pair flow with the on-disk .npy pair cache
+# PDCNetAux: pair flow over a workspace, device-resident, with the on-disk .npy pair cache
 # --------------------------------------------------------------------------------------------------
 def chunks(lst, n):
     for i in range(0, len(lst), n):
@@ -198,11 +198,21 @@ def chunks(lst, n):
 
 
 class PDCNetAux:
-    """ofgen_keyframe_inpaint.py:549-653.  `video` needs `.size_hw` and `.get_raw_frame(i) -> BGR uint8`;
-    index containers need `.indices` and `__len__` (the reference's VideoData / VideoFrameIndices)."""
+    """Pair flow + confidence over the frames of a workspace (ofgen_keyframe_inpaint.py:549-653).
+
+    The unit of work is a LIST OF PAIRS over a small set of frames (`pair_fields`): every distinct frame is decoded and
+    uploaded once (a bounded device-side frame cache survives across calls -- KeyframeConv's windows overlap), every
+    distinct frame is encoded once by the flow engine however many pairs use it (`PDCNetPlus.calc_pairs`), and flow and
+    confidence stay in HBM.  The reference's matrix builders (`calculate_multiple_to_one` -> f32[N,1,H,W,3],
+    `calculate_pairwise` -> f32[N,N,H,W,3], identity pairs = zero flow / confidence 1, the `pdcnet/{s:05d}-{t:05d}.npy`
+    cache with the same dtype and layout) are views assembled from that list; `keyframe_scores` / `ofgen.keyframe_conv`
+    reduce on the device instead and never build the matrix.
+
+    `video` needs `.size_hw` and `.get_raw_frame(i) -> BGR uint8`; index containers need `.indices` and `__len__`
+    (`workspace.VideoData` / `workspace.VideoFrameIndices`, or the reference's own classes)."""
 
     def __init__(self, pdcnet_model, workspace_dir: str, batch_size: int = 16, device=torch.device("cuda:0"),
-                 async_save: bool = False) -> None:
+                 async_save: bool = False, frame_cache: int = 64) -> None:
         """async_save=True (extension): the 4.7 MB-per-pair `.npy` dumps are written by a background
         thread from a private copy, so they leave the caller's critical path; `flush()` (also called by
         `load_cached`, `purge` and on deletion) waits for them.  Default: written before the call returns, like
@@ -213,25 +223,28 @@ class PDCNetAux:
             from concurrent.futures import ThreadPoolExecutor
             self._pool = ThreadPoolExecutor(max_workers=2, thread_name_prefix="ofx-npy")
         self.workspace_dir = workspace_dir
-        self.cached_pair = set()
         self.batch_size = batch_size
         self.device = device
         self.pdcnet_model = pdcnet_model.to(device)
         self.pair_dir = os.path.join(workspace_dir, "pdcnet")
-        if os.path.exists(self.pair_dir):
-            for f in glob.glob(os.path.join(self.pair_dir, "*.npy")):
-                name = os.path.split(f)[-1].split(".")[0]
-                s, t = name.split("-")
-                self.cached_pair.add((int(s), int(t)))
-        else:
-            os.makedirs(self.pair_dir, exist_ok=True)
+        os.makedirs(self.pair_dir, exist_ok=True)
+        self.cached_pair = set()
+        for f in glob.glob(os.path.join(self.pair_dir, "*.npy")):
+            s, t = os.path.basename(f)[:-4].split("-")
+            self.cached_pair.add((int(s), int(t)))
+        self._frames: "Dict[int, torch.Tensor]" = {}          # frame index -> uint8 RGB [H,W,3] on the device (LRU)
+        self._frame_cap = max(2, int(frame_cache))
+        self._frames_of = None                                # the video the cache belongs to
+
+    # ---- on-disk pair cache --------------------------------------------------------------------------
+    def _pair_path(self, s: int, t: int) -> str:
+        return os.path.join(self.pair_dir, f"{s:05d}-{t:05d}.npy")
 
     def _save(self, s: int, t: int, arr: np.ndarray) -> None:
-        path = os.path.join(self.pair_dir, f"{s:05d}-{t:05d}.npy")
         if self._pool is None:
-            np.save(path, arr)
+            np.save(self._pair_path(s, t), arr)
         else:
-            self._pending.append(self._pool.submit(np.save, path, np.array(arr, copy=True)))   # callers mutate `ret` (:995)
+            self._pending.append(self._pool.submit(np.save, self._pair_path(s, t), np.array(arr, copy=True)))   # callers mutate `ret` (:995)
 
     def flush(self) -> None:
         """Wait for queued `.npy` writes (no-op in the default synchronous mode); re-raises a failed write."""
@@ -256,7 +269,63 @@ class PDCNetAux:
     def load_cached(self, s, t):
         assert (s, t) in self.cached_pair
         self.flush()
-        return np.load(os.path.join(self.pair_dir, f"{s:05d}-{t:05d}.npy"))
+        return np.load(self._pair_path(s, t))
+
+    # ---- device-resident core ------------------------------------------------------------------------
+    def _device_frames(self, video, ids: Sequence[int]) -> torch.Tensor:
+        """uint8 RGB [n,H,W,3] on the device for the frame indices `ids`; each frame crosses PCIe once while it stays in
+        the cache."""
+        if self._frames_of is not video:
+            self._frames, self._frames_of = {}, video
+        missing = [i for i in ids if i not in self._frames]
+        if missing:
+            host = np.stack([np.ascontiguousarray(video.get_raw_frame(i)[:, :, ::-1]) for i in missing])   # BGR -> RGB (:591-592)
+            dev = torch.from_numpy(host).to(self.device)
+            for k, i in enumerate(missing):
+                self._frames[i] = dev[k]
+        for i in ids:                                         # refresh recency (dicts keep insertion order)
+            self._frames[i] = self._frames.pop(i)
+        out = torch.stack([self._frames[i] for i in ids])
+        while len(self._frames) > self._frame_cap:
+            self._frames.pop(next(iter(self._frames)))
+        return out
+
+    @torch.no_grad()
+    def pair_fields(self, video, pairs: Sequence[Tuple[int, int]]):
+        """(flow f32[P,H,W,2], confidence f32[P,H,W]) ON THE DEVICE for the (source, target) pairs, in order; flow p
+        lives on target's grid and points into source (PDCNetPlus.calc's orientation).  Pairs are processed in slices of
+        whole frames so that one slice's frame set fits the engine's per-call limit."""
+        pairs = [(int(s), int(t)) for s, t in pairs]
+        if not pairs:
+            h, w = video.size_hw
+            return (torch.zeros((0, h, w, 2), device=self.device), torch.zeros((0, h, w), device=self.device))
+        model = self.pdcnet_model
+        if not hasattr(model, "calc_pairs"):                  # a foreign of-algo with the reference's duck type only
+            flows, confs = [], []
+            for batch in chunks(pairs, self.batch_size):
+                src = self._device_frames(video, [s for s, _ in batch])
+                tgt = self._device_frames(video, [t for _, t in batch])
+                fl, cf = model.calc_batch(src, tgt)
+                flows.append(torch.as_tensor(fl, device=self.device))
+                confs.append(torch.as_tensor(cf, device=self.device))
+            return torch.cat(flows), torch.cat(confs)
+        ids = sorted({i for p in pairs for i in p})
+        local = {g: l for l, g in enumerate(ids)}
+        frames = self._device_frames(video, ids)
+        return model.calc_pairs(frames, [(local[s], local[t]) for s, t in pairs])
+
+    def calculate_given_pairs(self, video, to_calculate_pairs: List[Tuple[int, int]], s2i_map: Dict[int, int],
+                              t2i_map: Dict[int, int], ret: np.ndarray):
+        """:585-600: fills `ret[s2i[s], t2i[t]] = (fx, fy, confidence)` for the listed pairs and writes each to the
+        pair cache."""
+        if not to_calculate_pairs:
+            return
+        flow, conf = self.pair_fields(video, to_calculate_pairs)
+        packed = torch.cat([flow, conf[..., None]], dim=-1).cpu().numpy()      # one D2H copy, [P,H,W,3]
+        for k, (s, t) in enumerate(to_calculate_pairs):
+            slot = ret[s2i_map[s], t2i_map[t]]
+            slot[...] = packed[k]
+            self._save(s, t, slot)
 
     def calcualte_single(self, video, s, t):          # (sic) the reference's spelling, :576
         if (s, t) in self.cached_pair:
@@ -266,85 +335,94 @@ class PDCNetAux:
         self.cached_pair.add((s, t))
         return ret[0, 0]
 
-    def calculate_given_pairs(self, video, to_calculate_pairs: List[Tuple[int, int]], s2i_map: Dict[int, int],
-                              t2i_map: Dict[int, int], ret: np.ndarray):
-        if len(to_calculate_pairs) > 1 and hasattr(self.pdcnet_model, "calc_pairs"):
-            # fast path ("next" row f1): every distinct frame is decoded, uploaded and encoded once; the
-            # N*(N-1) ordered pairs of a KeyframeConv window share N feature / context maps
-            ids = sorted({i for p in to_calculate_pairs for i in p})
-            lm = {g: l for l, g in enumerate(ids)}
-            frames = np.stack([np.ascontiguousarray(video.get_raw_frame(i)[:, :, ::-1]) for i in ids])     # RGB
-            flow, conf = self.pdcnet_model.calc_pairs(torch.from_numpy(frames).to(self.device),
-                                                      [(lm[s], lm[t]) for s, t in to_calculate_pairs])
-            flow, conf = flow.cpu().numpy(), conf.cpu().numpy()
-            for i, (s, t) in enumerate(to_calculate_pairs):
-                si, ti = s2i_map[s], t2i_map[t]
-                ret[si, ti, :, :, 0:2] = flow[i]
-                ret[si, ti, :, :, 2] = conf[i]
-                self._save(s, t, ret[si, ti])
-            return
-        for pair_batch in chunks(to_calculate_pairs, self.batch_size):
-            bs = len(pair_batch)
-            inp_source = np.zeros((bs, *video.size_hw, 3), dtype=np.uint8)
-            inp_target = np.zeros((bs, *video.size_hw, 3), dtype=np.uint8)
-            for i, (s, t) in enumerate(pair_batch):
-                inp_source[i] = video.get_raw_frame(s)[:, :, ::-1]     # BGR -> RGB (:591-592)
-                inp_target[i] = video.get_raw_frame(t)[:, :, ::-1]
-            flow_est, confidence = self.pdcnet_model.calc_batch(torch.from_numpy(inp_source).to(self.device),
-                                                                torch.from_numpy(inp_target).to(self.device))
-            for i, (s, t) in enumerate(pair_batch):
-                si, ti = s2i_map[s], t2i_map[t]
-                ret[si, ti, :, :, 0:2] = flow_est[i]
-                ret[si, ti, :, :, 2] = confidence[i]
-                self._save(s, t, ret[si, ti])
+    def _matrix(self, video, sources: Sequence[int], targets: Sequence[int]) -> np.ndarray:
+        """f32[len(sources), len(targets), H, W, 3]: cached pairs from disk, missing ones computed (and cached), identity
+        pairs = zero flow with confidence 1 (:621-623, :649-651)."""
+        s2i = {s: i for i, s in enumerate(sources)}
+        t2i = {t: j for j, t in enumerate(targets)}
+        todo = [(s, t) for s in sources for t in targets if s != t and (s, t) not in self.cached_pair]
+        ret = np.zeros((len(sources), len(targets), *video.size_hw, 3), dtype=np.float32)
+        fresh = set(todo)
+        self.calculate_given_pairs(video, todo, s2i, t2i, ret)
+        for s in sources:
+            for t in targets:
+                if s == t:
+                    ret[s2i[s], t2i[t], :, :, 2] = 1
+                elif (s, t) not in fresh:
+                    ret[s2i[s], t2i[t]] = self.load_cached(s, t)
+        self.cached_pair.update(todo)
+        return ret
 
     def calculate_multiple_to_one(self, video, source_indices, target_index: int) -> np.ndarray:
         """-> f32[N, 1, H, W, 3] (:602-625)."""
-        to_calc: List[Tuple[int, int]] = []
-        n = len(source_indices)
-        s2i, t2i = {}, {target_index: 0}
-        for i, s in enumerate(source_indices.indices):
-            s2i[s] = i
-            if s != target_index and (s, target_index) not in self.cached_pair:
-                to_calc.append((s, target_index))
-        ret = np.zeros((n, 1, *video.size_hw, 3), dtype=np.float32)
-        self.calculate_given_pairs(video, to_calc, s2i, t2i, ret)
-        for i, s in enumerate(source_indices.indices):
-            if s != target_index:
-                if (s, target_index) in self.cached_pair:
-                    ret[i, 0] = self.load_cached(s, target_index)
-            else:
-                ret[i, 0, :, :, 0:2] = 0
-                ret[i, 0, :, :, 2] = 1
-        self.cached_pair.update(to_calc)
-        return ret
+        return self._matrix(video, list(source_indices.indices), [target_index])
 
     def calculate_pairwise(self, video, indices) -> np.ndarray:
-        """-> f32[N, N, H, W, 3] (:627-653)."""
-        n = len(indices)
-        to_calc: List[Tuple[int, int]] = []
-        s2i, t2i = {}, {}
-        for i, s in enumerate(indices.indices):
-            s2i[s] = i
-            for j, t in enumerate(indices.indices):
-                t2i[t] = j
-                if s != t and (s, t) not in self.cached_pair:
-                    to_calc.append((s, t))
-        ret = np.zeros((n, n, *video.size_hw, 3), dtype=np.float32)
-        self.calculate_given_pairs(video, to_calc, s2i, t2i, ret)
-        for i, s in enumerate(indices.indices):
-            for j, t in enumerate(indices.indices):
-                if s != t:
-                    if (s, t) in self.cached_pair:
-                        ret[i, j] = self.load_cached(s, t)
-                else:
-                    ret[i, j, :, :, 0:2] = 0
-                    ret[i, j, :, :, 2] = 1
-        self.cached_pair.update(to_calc)
-        return ret
+        """-> f32[N, N, H, W, 3] (:627-653).  Compatibility view (1.06 GB for a 15-frame window at 512x768):
+        `keyframe_scores_device` answers KeyframeConv's question without it."""
+        return self._matrix(video, list(indices.indices), list(indices.indices))
+
+    # ---- KeyframeConv's reduction, on the device -------------------------------------------------------
+    @torch.no_grad()
+    def keyframe_scores_device(self, video, indices, save_pairs: bool = False) -> torch.Tensor:
+        """`einops.reduce(flow_mat[:, :, :, :, 2], 's t h w -> s', 'sum')` of KeyframeConv (:666) for the window
+        `indices`, as a float64 tensor [N] on the device: the N*(N-1) confidence maps are reduced where they are
+        produced (`ofx_conf_sum`, f64 accumulation); the identity pair contributes H*W.  Pairs already in the cache are
+        read back from disk; with save_pairs=True the fresh ones are also written (keeps the workspace interchangeable
+        with the reference at 4.7 MB per pair)."""
+        ids = list(indices.indices)
+        pos = {s: i for i, s in enumerate(ids)}
+        h, w = video.size_hw
+        scores = torch.full((len(ids),), float(h * w), dtype=torch.float64, device=self.device)
+        fresh = [(s, t) for s in ids for t in ids if s != t and (s, t) not in self.cached_pair]
+        if fresh:
+            flow, conf = self.pair_fields(video, fresh)
+            sums = ops.conf_sum(conf[..., None].contiguous(), 0)             # f64 [P]
+            owner = torch.tensor([pos[s] for s, _ in fresh], device=self.device)
+            scores.index_add_(0, owner, sums)
+            if save_pairs:
+                packed = torch.cat([flow, conf[..., None]], dim=-1).cpu().numpy()
+                for k, (s, t) in enumerate(fresh):
+                    self._save(s, t, packed[k])
+                self.cached_pair.update(fresh)
+        fresh_set = set(fresh)
+        old = [(s, t) for s in ids for t in ids if s != t and (s, t) not in fresh_set]
+        for batch in chunks(old, 16):
+            conf = torch.from_numpy(np.stack([self.load_cached(s, t)[:, :, 2] for s, t in batch])).to(self.device)
+            sums = ops.conf_sum(conf[..., None].contiguous(), 0)
+            scores.index_add_(0, torch.tensor([pos[s] for s, _ in batch], device=self.device), sums)
+        return scores
 
     def keyframe_scores(self, flow_mat: np.ndarray) -> np.ndarray:
-        """`einops.reduce(flow_mat[..., 2], 's t h w -> s', 'sum')` of KeyframeConv (:666) on the device."""
+        """The same reduction for a matrix the caller already holds on the host (f32[N,M,H,W,3])."""
         n, m, h, w, _ = flow_mat.shape
         per = ops.conf_sum(_dev(flow_mat, self.device).reshape(n * m, h, w, 3), 2).reshape(n, m).sum(1)
         return per.cpu().numpy()
+
+
+def keyframe_conv(pdcnet: PDCNetAux, workspace: str, video, frames, kernel_size: int = 17, stride: int = 8, dilation: int = 2,
+                  save_pairs: bool = False):
+    """`KeyframeConv` (ofgen_keyframe_inpaint.py:655-674): slide a window over `frames`, and from every window keep the
+    frame whose confidence towards all the others is largest.  `workspace` caches the result as `{idx:05d}.png` files
+    exactly like the reference (a non-empty directory short-circuits the computation, :656-660).
+
+    Device-resident: per window the frames are uploaded once (and stay cached across the overlapping windows), flows for
+    all ordered pairs share one encoder pass per frame, the `s t h w -> s` sum and the arg-max run on the device; the
+    only thing that crosses PCIe per window is the winner's position.  Ties go to the earliest frame (np.argmax)."""
+    from .workspace import VideoFrameIndices, _write_png_bgr
+    if os.path.exists(workspace):
+        found = [int(os.path.basename(f).split(".")[0]) for f in glob.glob(os.path.join(workspace, "*.png"))]
+        if found:
+            return VideoFrameIndices(found)
+    else:
+        os.makedirs(workspace)
+    winners = set()
+    for window in frames.conv_indices(kernel_size, stride, dilation):
+        scores = pdcnet.keyframe_scores_device(video, window, save_pairs=save_pairs)
+        winners.add(window.indices[int(torch.argmax(scores).item())])       # first maximum, like np.argmax (:667)
+    for idx in winners:
+        _write_png_bgr(os.path.join(workspace, f"{idx:05d}.png"), video.get_raw_frame(idx))
+    return VideoFrameIndices(winners)
+
+
+KeyframeConv = keyframe_conv          # the reference's spelling

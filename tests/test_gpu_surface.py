@@ -288,3 +288,66 @@ def test_calc_pairs_honours_the_per_call_pair_limit(algo, monkeypatch):
     got_f, got_c = algo.calc_pairs(dev, pairs)
     assert calls and max(calls) <= 4 and sum(calls) == 6
     assert (got_f - want_f).abs().max().item() < 1e-4 and (got_c - want_c).abs().max().item() < 1e-4
+
+
+def test_keyframe_conv_device_resident_over_a_workspace(algo, tmp_path):
+    """KeyframeConv (ofgen_keyframe_inpaint.py:655-674) over a `workspace.VideoData`: windows from `conv_indices`, scores
+    reduced on the device.  Held to the reference's host formulation -- build the [N,N,H,W,3] matrix with
+    `calculate_pairwise`, `einops.reduce(..., 's t h w -> s', 'sum')`, np.argmax -- on the same workspace."""
+    from sd_animation_optical_flow_amd import ofgen
+    from sd_animation_optical_flow_amd.workspace import VideoData, VideoFrameIndices
+    H, W = 64, 96
+    g = torch.Generator().manual_seed(77)
+    base = torch.nn.functional.avg_pool2d(torch.rand((1, 3, H + 40, W + 40), generator=g), 5, 1, 2)
+    base = ((base - base.min()) / (base.max() - base.min()) * 255).round().to(torch.uint8)[0].permute(1, 2, 0).numpy()
+    shifts = [(0, 0), (1, 2), (3, 3), (9, 1), (10, 2), (11, 4), (18, 9)]
+    frames = [np.ascontiguousarray(base[20 + dy:20 + dy + H, 20 + dx:20 + dx + W]) for dy, dx in shifts]
+    video = VideoData(frames, (W, H), str(tmp_path / "ws"))
+    aux = ofgen.PDCNetAux(algo, video.workspace_dir, batch_size=4)
+    idx = VideoFrameIndices.from_n(video.num_frames)
+    kf_dir = str(tmp_path / "ws" / "keyframes")
+    got = ofgen.keyframe_conv(aux, kf_dir, video, idx, kernel_size=5, stride=2, dilation=2)
+    # nothing but the winners' PNGs is written unless asked: the N*(N-1) pair dumps (4.7 MB each at 512x768) stay off disk
+    assert os.listdir(tmp_path / "ws" / "pdcnet") == []
+    want = set()
+    host = ofgen.PDCNetAux(algo, str(tmp_path / "host"), batch_size=4)
+    for window in idx.conv_indices(5, 2, 2):
+        mat = host.calculate_pairwise(video, window)
+        scores = mat[:, :, :, :, 2].sum(axis=(1, 2, 3), dtype=np.float64)
+        dev_scores = aux.keyframe_scores_device(video, window).cpu().numpy()
+        assert np.allclose(dev_scores, scores, rtol=1e-5), (window.indices, dev_scores, scores)
+        want.add(window.indices[int(np.argmax(scores))])
+    assert got.indices == sorted(want)
+    assert sorted(os.listdir(kf_dir)) == [f"{i:05d}.png" for i in sorted(want)]
+    assert np.array_equal(VideoData(None, (W, H), str(tmp_path / "ws")).get_raw_frame(got.indices[0]), frames[got.indices[0]])
+    # a populated result directory short-circuits the computation (:656-660)
+    again = ofgen.KeyframeConv(None, kf_dir, None, None)
+    assert again.indices == got.indices
+    # save_pairs=True leaves a workspace the reference's PDCNetAux can continue from; cached pairs are reused
+    aux.keyframe_scores_device(video, VideoFrameIndices([0, 1, 2]), save_pairs=True)
+    assert len(os.listdir(tmp_path / "ws" / "pdcnet")) == 6 and (1, 2) in aux.cached_pair
+    s1 = aux.keyframe_scores_device(video, VideoFrameIndices([0, 1, 2])).cpu().numpy()
+    s0 = host.calculate_pairwise(video, VideoFrameIndices([0, 1, 2]))[..., 2].sum(axis=(1, 2, 3), dtype=np.float64)
+    assert np.allclose(s1, s0, rtol=1e-5)
+
+
+def test_keyframe_conv_ties_go_to_the_earliest_frame(cuda, tmp_path):
+    """np.argmax keeps the first maximum (:667): with an of-algo whose confidence is the same for every pair every window
+    elects its first member."""
+    from sd_animation_optical_flow_amd import ofgen
+    from sd_animation_optical_flow_amd.workspace import VideoData, VideoFrameIndices
+
+    class Flat:
+        def to(self, device):
+            return self
+
+        def calc_pairs(self, frames, pairs, **kw):
+            n, h, w, _ = frames.shape
+            return (torch.zeros((len(pairs), h, w, 2), device=frames.device), torch.full((len(pairs), h, w), 0.5, device=frames.device))
+
+    rng = np.random.default_rng(1)
+    frames = [rng.integers(0, 256, (16, 24, 3), dtype=np.uint8) for _ in range(9)]
+    video = VideoData(frames, (24, 16), str(tmp_path / "ws"))
+    aux = ofgen.PDCNetAux(Flat(), video.workspace_dir)
+    got = ofgen.keyframe_conv(aux, str(tmp_path / "kf"), video, VideoFrameIndices.from_n(9), kernel_size=4, stride=3, dilation=1)
+    assert got.indices == [0, 3, 6]

@@ -1,0 +1,84 @@
+"""CPU: the reference's workspace formats -- `VideoData` directory layout and PNG round trip,
+`VideoFrameIndices` window enumeration (hand-derived from ofgen_keyframe_inpaint.py:483-541)."""
+import os
+
+import numpy as np
+import pytest
+
+from sd_animation_optical_flow_amd.workspace import VideoData, VideoFrameIndices
+
+
+def _frames(n, h=24, w=32, seed=0):
+    rng = np.random.default_rng(seed)
+    return [rng.integers(0, 256, (h, w, 3), dtype=np.uint8) for _ in range(n)]
+
+
+def test_video_data_layout_and_round_trip(tmp_path):
+    frames = _frames(7)
+    ws = str(tmp_path / "ws")
+    v = VideoData(frames, (32, 24), ws, keep_every=3)
+    assert v.num_frames == 3 and v.size_hw == (24, 32) and v.fps == 10.0
+    for d in ("raw-frames", "ai-frames", "pdcnet", "crossattn", "seed"):
+        assert os.path.isdir(os.path.join(ws, d))
+    assert sorted(os.listdir(os.path.join(ws, "raw-frames"))) == ["00000.png", "00001.png", "00002.png"]
+    for k, src in enumerate((0, 3, 6)):
+        assert np.array_equal(v.get_raw_frame(k), frames[src])           # lossless, BGR in memory
+    # the file on disk is an ordinary RGB PNG (what cv2.imwrite produces from a BGR array)
+    from PIL import Image
+    rgb = np.asarray(Image.open(os.path.join(ws, "raw-frames", "00001.png")))
+    assert np.array_equal(rgb, frames[3][:, :, ::-1])
+    # ai-frames: generated() is file presence
+    assert not v.generated(1) and v.get_ai_frame(1) is None
+    v.put_ai_frame(1, frames[5])
+    assert v.generated(1) and np.array_equal(v.get_ai_frame(1), frames[5])
+    with pytest.raises(AssertionError):
+        v.get_raw_frame(3)
+    # reopening an existing workspace counts the frames instead of re-extracting
+    v2 = VideoData(None, (32, 24), ws)
+    assert v2.num_frames == 3 and np.array_equal(v2.get_raw_frame(2), frames[6])
+    v2.put_kv(2, {"k": [1, 2, 3]})
+    assert v2.get_kv(2) == {"k": [1, 2, 3]}
+    v2.remove_kv(2)
+    assert not os.path.exists(os.path.join(ws, "crossattn", "00002.bin"))
+    with pytest.raises(ValueError):
+        VideoData(_frames(1, 10, 10), (32, 24), str(tmp_path / "bad"))
+
+
+def test_max_len_and_existing_files_are_kept(tmp_path):
+    ws = str(tmp_path / "ws")
+    v = VideoData(_frames(40), (32, 24), ws, keep_every=1, max_len_sec=1, fps=8.0)
+    assert v.num_frames == 9                                   # the reference stops after ctr_valid >= fps * seconds
+    before = os.path.getmtime(os.path.join(ws, "raw-frames", "00000.png"))
+    VideoData(_frames(3, seed=5), (32, 24), ws)                # same workspace again: existing PNGs are not rewritten
+    assert os.path.getmtime(os.path.join(ws, "raw-frames", "00000.png")) == before
+
+
+def test_conv_indices_windows():
+    """indices[idx : idx + kernel][0::dilation], idx += stride (:493-497)."""
+    idx = VideoFrameIndices.from_n(40)
+    got = [w.indices for w in idx.conv_indices(17, 8, 2)]
+    assert got == [list(range(0, 17, 2)), list(range(8, 25, 2)), list(range(16, 33, 2)), list(range(24, 40, 2)),
+                   [32, 34, 36, 38]]
+    assert [w.indices for w in VideoFrameIndices([5, 1, 9, 1]).conv_indices(2, 1, 1)] == [[1, 5], [5, 9], [9]]
+    assert [w.indices for w in VideoFrameIndices([]).conv_indices()] == []
+    sparse = VideoFrameIndices([3, 10, 11, 40, 41, 42, 90])
+    assert [w.indices for w in sparse.conv_indices(4, 3, 1)] == [[3, 10, 11, 40], [40, 41, 42, 90], [90]]
+
+
+def test_index_set_operations_and_adjacent_frames():
+    a = VideoFrameIndices([4, 2, 2, 8])
+    assert a.indices == [2, 4, 8] and len(a) == 3
+    a.add(6)
+    a.add(VideoFrameIndices([1, 8]))
+    assert a.indices == [1, 2, 4, 6, 8]
+    a.remove(VideoFrameIndices([2, 100]))
+    assert a.indices == [1, 4, 6, 8]
+    idx = VideoFrameIndices(range(0, 100, 10))
+    assert idx.adjacent_frames(34, 3).indices == [20, 30, 40]
+    assert idx.adjacent_frames(-5, 2).indices == [0, 10]
+    # the reference's range(0, len - n) never offers the last run: the closest run to 95 is [70, 80], not [80, 90]
+    assert idx.adjacent_frames(95, 2).indices == [70, 80]
+    assert idx.adjacent_frames(50, 20) is idx
+    # ties keep the first run
+    assert VideoFrameIndices([0, 10, 20, 30]).adjacent_frames(15, 2).indices == [10, 20]
+    assert VideoFrameIndices([0, 10, 20, 30]).adjacent_frames(10, 1).indices == [10]
