@@ -17,7 +17,7 @@
  *   ofx_raft_*                  RAFT/core/raft.py:86-144 ; ofgen_keyframe_inpaint.py:47-71 (RAFT_2)
  *   ofx_warp_*                  pdcnet_of.py:34-42 ; ofgen_keyframe_inpaint.py:92-98 (cv2.remap)
  *   ofx_generate_mask, ofx_dilate_u8, ofx_expand_mask, ofx_travel_distance, ofx_merge_images,
- *   ofx_mix_frames, ofx_conf_sum, ofx_compose_step
+ *   ofx_mix_frames, ofx_conf_sum
  *                               ofgen_keyframe_inpaint.py:113-133,237-248,306-322,676-688,968-973,995-1027
  *
  * Layout conventions: images and flow are HWC ("channels-last"); network activations are
@@ -220,10 +220,16 @@ int ofx_preprocess_u8(const uint8_t* img, float* out, long npix, int bgr, void* 
 
 /* ---------------------------------------------------------------- correlation */
 /* vol0[b,i,j] = <f1[b,i,:], f2[b,j,:]> / sqrt(D) and the avg-pooled pyramid (CorrBlock.__init__).
- * f1,f2: [B, h*w, D] (NHWC); pyr[l]: [B*h*w, h_l*w_l], h_l = h >> l (floor). levels in [1,4]. */
+ * f1,f2: [B, h*w, D] (NHWC).  pyr[l] holds, for each of the B*h*w source pixels, that pixel's h_l x w_l slice
+ * (h_l = h >> l, floor) in the BLOCKED layout the lookup reads: 4-row x 8-column blocks of 32 floats (128 bytes = one
+ * HBM line), blocks row-major, padding elements zero:
+ *     slice[((y / 4) * ceil(w_l / 8) + x / 8) * 32 + (y % 4) * 8 + (x % 8)] = corr(pixel, (y, x))
+ * so pyr[l] is [B*h*w][ofx_corr_slice_floats(h_l, w_l)] and must be 16-byte aligned.  levels in [1,4]. */
+int ofx_corr_slice_floats(int h_l, int w_l);      /* ceil(h_l/4) * ceil(w_l/8) * 32 */
 int ofx_corr_volume(const float* f1, const float* f2, float* const* pyr, int B, int h, int w, int D,
                     int levels, void* stream);
-/* CorrBlock.__call__: out[m, l*(2r+1)^2 + i*(2r+1) + j] for coords [B*h*w][2]; out row stride ldo */
+/* CorrBlock.__call__ on the blocked pyramid: out[m, l*(2r+1)^2 + i*(2r+1) + j] for coords [B*h*w][2];
+ * out row stride ldo */
 int ofx_corr_lookup(const float* const* pyr, const float* coords, float* out, int ldo, int B, int h,
                     int w, int levels, int radius, void* stream);
 /* alt_cuda_corr.forward: fmap1 [B,H1,W1,C], fmap2 [B,H2,W2,C], coords [B,N,H1,W1,2] ->

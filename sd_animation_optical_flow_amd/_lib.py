@@ -82,6 +82,7 @@ SIGNATURES = {
     "ofx_inorm_stats": (_i, [_p, _i, _p, _p, _p, _i, _l, _i, _f, _p]),
     "ofx_inorm_apply": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _l, _i, _i, _p]),
     "ofx_preprocess_u8": (_i, [_p, _p, _l, _i, _p]),
+    "ofx_corr_slice_floats": (_i, [_i, _i]),
     "ofx_corr_volume": (_i, [_p, _p, C.POINTER(_p), _i, _i, _i, _i, _i, _p]),
     "ofx_corr_lookup": (_i, [C.POINTER(_p), _p, _p, _i, _i, _i, _i, _i, _i, _p]),
     "ofx_local_corr_fwd": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p]),

@@ -5,101 +5,127 @@
 //                      through the batched mode of the implicit-GEMM kernel (conv.hip); this file adds
 //                      the 3-level average-pool pyramid, computed from one read of level 0 with the
 //                      intermediate levels held in LDS.
-//   lookup             RAFT/core/corr.py:29-50 ; RAFT/core/utils/utils.py:57-71.  HBM-bound gather:
-//                      per pixel, four (2r+2)^2 windows (40-byte row runs) -> 324 contiguous floats.
-//                      One wavefront per pixel: the 400 window taps are fetched once into LDS (all 81
-//                      samples of a level share one fractional offset), the 324 outputs are written as
-//                      one coalesced 1296-byte run.
+//   layout             every pixel's slice of every level is stored in 4-row x 8-column BLOCKS of 128 bytes (one
+//                      HBM line): element (y, x) of an h_l x w_l slice sits at
+//                      ((y/4) * ceil(w_l/8) + x/8) * 32 + (y%4) * 8 + x%8, padding elements are zero.  Level 0 comes
+//                      out of the GEMM in this order for free: the rows of fmap2 (the GEMM's B operand) are permuted
+//                      once (ofx_corr_block_rows).
+//   lookup             RAFT/core/corr.py:29-50 ; RAFT/core/utils/utils.py:57-71.  Per pixel, four 10x10 windows ->
+//                      324 contiguous floats.  One wavefront per pixel: the blocks a window touches are fetched with
+//                      dense 16-byte lane loads into LDS (all 81 samples of a level share one fractional offset), the
+//                      324 outputs are written as one coalesced 1296-byte run.
 //   local correlation  RAFT/alt_cuda_corr/correlation_kernel.cu:18-119 (forward only; the backward
 //                      kernel is training-only and never reached by the reference's no_grad callers).
 #include "ofx_internal.h"
+
+#include <algorithm>
+#include <cstdlib>
 
 namespace {
 
 // ------------------------------------------------------------------------------------------
 // pyramid levels 1..3 from level 0
 // ------------------------------------------------------------------------------------------
+__host__ __device__ __forceinline__ int blocked_index(int y, int x, int wb) {
+    return (((y >> 2) * wb + (x >> 3)) << 5) + ((y & 3) << 3) + (x & 7);
+}
+
 struct PoolArgs {
     const float* l0;
-    float* l1;
-    float* l2;
-    float* l3;
-    int h0, w0, h1, w1, h2, w2, h3, w3;
-    int levels;   // total pyramid levels (2..4)
+    float* lv[4];             // lv[1..3]: outputs
+    int h[4], w[4], wb[4];
+    int slice[4];             // floats per pixel slice per level
+    int levels;               // total pyramid levels (2..4)
 };
+
+// LDS map (row-major, h x w) -> one blocked slice in HBM, padding elements written as zeros, 16-byte stores
+__device__ __forceinline__ void store_blocked(const float* __restrict__ smap, float* __restrict__ dst, int h, int w, int wb, int slice) {
+    for (int e = threadIdx.x * 4; e < slice; e += 256 * 4) {
+        const int blk = e >> 5, off = e & 31;
+        const int by = blk / wb, bx = blk - by * wb;
+        const int y = (by << 2) + (off >> 3), x = (bx << 3) + (off & 7);   // x % 4 == 0: four consecutive columns
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (y < h) {
+            const float* r = smap + y * w + x;
+            if (x < w) v.x = r[0];
+            if (x + 1 < w) v.y = r[1];
+            if (x + 2 < w) v.z = r[2];
+            if (x + 3 < w) v.w = r[3];
+        }
+        *reinterpret_cast<float4*>(dst + e) = v;
+    }
+}
 
 __global__ __launch_bounds__(256) void pyramid_pool_kernel(const PoolArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    float* s1 = lds;                       // level 1 map
-    float* s2 = lds + a.h1 * a.w1;         // level 2 map
-    const long p = blockIdx.x;             // source pixel (row of the volume)
-    const float* src = a.l0 + p * (long)a.h0 * a.w0;
-    float* d1 = a.l1 + p * (long)a.h1 * a.w1;
-    const int n1 = a.h1 * a.w1;
-    if ((a.w0 & 3) == 0) {
-        // rows are 16-byte aligned: one thread pools two horizontally adjacent outputs from two float4 loads,
-        // four such pairs per trip so that 8 x 16 B are in flight per lane (same additions, same order)
-        const int wp = a.w1 >> 1;                  // output pairs per row
-        const int npair = a.h1 * wp;
-        for (int i0 = 0; i0 < npair; i0 += 4 * 256) {
-            float4 t[4], u[4];
-            int o[4];
+    float* s1 = lds;                          // level 1 map, row-major
+    float* s2 = s1 + a.h[1] * a.w[1];         // level 2
+    float* s3 = s2 + a.h[2] * a.w[2];         // level 3
+    const long p = blockIdx.x;                // source pixel (row of the volume)
+    const float* src = a.l0 + p * (long)a.slice[0];
+    // level 1 from ONE read of level 0: a 4x8 block pools into a 2x4 patch, so an item is (block, row pair, column half):
+    // two 16-byte loads -> two outputs; four items per trip keep 8 x 16 B in flight per lane
+    const int nitem = (a.slice[0] >> 5) << 2;
+    const int h1 = a.h[1], w1 = a.w[1], wb0 = a.wb[0];
+    for (int i0 = 0; i0 < nitem; i0 += 4 * 256) {
+        float4 t[4], u[4];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int i = min(i0 + q * 256 + (int)threadIdx.x, npair - 1);
-                const int y = i / wp, x2 = i - y * wp;
-                o[q] = y * a.w1 + 2 * x2;
-                const float* r = src + (long)(2 * y) * a.w0 + 4 * x2;
-                t[q] = *reinterpret_cast<const float4*>(r);
-                u[q] = *reinterpret_cast<const float4*>(r + a.w0);
-            }
+        for (int q = 0; q < 4; ++q) {
+            const int i = min(i0 + q * 256 + (int)threadIdx.x, nitem - 1);
+            const float* r = src + ((i >> 2) << 5) + (((i >> 1) & 1) << 4) + ((i & 1) << 2);
+            t[q] = *reinterpret_cast<const float4*>(r);
+            u[q] = *reinterpret_cast<const float4*>(r + 8);
+        }
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                if (i0 + q * 256 + (int)threadIdx.x >= npair) continue;
-                float2 v;
-                v.x = (((t[q].x + t[q].y) + u[q].x) + u[q].y) * 0.25f;   // avg_pool2d: window sum, then /4
-                v.y = (((t[q].z + t[q].w) + u[q].z) + u[q].w) * 0.25f;
-                *reinterpret_cast<float2*>(d1 + o[q]) = v;
-                *reinterpret_cast<float2*>(s1 + o[q]) = v;
-            }
+        for (int q = 0; q < 4; ++q) {
+            const int i = i0 + q * 256 + (int)threadIdx.x;
+            if (i >= nitem) continue;
+            const int b0 = i >> 2;
+            const int by = b0 / wb0, bx = b0 - by * wb0;
+            const int y1 = (by << 1) + ((i >> 1) & 1), x1 = (bx << 2) + ((i & 1) << 1);
+            if (y1 >= h1) continue;
+            if (x1 < w1) s1[y1 * w1 + x1] = (((t[q].x + t[q].y) + u[q].x) + u[q].y) * 0.25f;     // avg_pool2d: window sum, then /4
+            if (x1 + 1 < w1) s1[y1 * w1 + x1 + 1] = (((t[q].z + t[q].w) + u[q].z) + u[q].w) * 0.25f;
         }
-    } else
-    for (int i = threadIdx.x; i < n1; i += 256) {
-        const int y = i / a.w1, x = i - y * a.w1;
-        float2 t, u;
-        if (a.w0 & 1) {   // odd row length: rows are not 8-byte aligned
-            const float* q = src + (long)(2 * y) * a.w0 + 2 * x;
-            t = make_float2(q[0], q[1]);
-            u = make_float2(q[a.w0], q[a.w0 + 1]);
-        } else {
-            t = *reinterpret_cast<const float2*>(src + (long)(2 * y) * a.w0 + 2 * x);
-            u = *reinterpret_cast<const float2*>(src + (long)(2 * y + 1) * a.w0 + 2 * x);
-        }
-        const float v = (((t.x + t.y) + u.x) + u.y) * 0.25f;   // avg_pool2d: window sum, then /4
-        d1[i] = v;
-        s1[i] = v;
     }
+    __syncthreads();
+    store_blocked(s1, a.lv[1] + p * (long)a.slice[1], h1, w1, a.wb[1], a.slice[1]);
     if (a.levels < 3) return;
-    __syncthreads();
-    float* d2 = a.l2 + p * (long)a.h2 * a.w2;
-    const int n2 = a.h2 * a.w2;
-    for (int i = threadIdx.x; i < n2; i += 256) {
-        const int y = i / a.w2, x = i - y * a.w2;
-        const float* r0 = s1 + (2 * y) * a.w1 + 2 * x;
-        const float* r1 = r0 + a.w1;
-        const float v = (((r0[0] + r0[1]) + r1[0]) + r1[1]) * 0.25f;
-        d2[i] = v;
-        s2[i] = v;
+    const int h2 = a.h[2], w2 = a.w[2];
+    for (int i = threadIdx.x; i < h2 * w2; i += 256) {
+        const int y = i / w2, x = i - y * w2;
+        const float* r0 = s1 + (2 * y) * w1 + 2 * x;
+        const float* r1 = r0 + w1;
+        s2[i] = (((r0[0] + r0[1]) + r1[0]) + r1[1]) * 0.25f;
     }
-    if (a.levels < 4) return;
     __syncthreads();
-    float* d3 = a.l3 + p * (long)a.h3 * a.w3;
-    const int n3 = a.h3 * a.w3;
-    for (int i = threadIdx.x; i < n3; i += 256) {
-        const int y = i / a.w3, x = i - y * a.w3;
-        const float* r0 = s2 + (2 * y) * a.w2 + 2 * x;
-        const float* r1 = r0 + a.w2;
-        d3[i] = (((r0[0] + r0[1]) + r1[0]) + r1[1]) * 0.25f;
+    store_blocked(s2, a.lv[2] + p * (long)a.slice[2], h2, w2, a.wb[2], a.slice[2]);
+    if (a.levels < 4) return;
+    const int h3 = a.h[3], w3 = a.w[3];
+    for (int i = threadIdx.x; i < h3 * w3; i += 256) {
+        const int y = i / w3, x = i - y * w3;
+        const float* r0 = s2 + (2 * y) * w2 + 2 * x;
+        const float* r1 = r0 + w2;
+        s3[i] = (((r0[0] + r0[1]) + r1[0]) + r1[1]) * 0.25f;
+    }
+    __syncthreads();
+    store_blocked(s3, a.lv[3] + p * (long)a.slice[3], h3, w3, a.wb[3], a.slice[3]);
+}
+
+// fmap rows (pixel order, [n][h*w][D]) -> blocked column order of the volume ([n][slice][D], zero rows for padding)
+__global__ __launch_bounds__(256) void block_rows_kernel(const float* __restrict__ src, float* __restrict__ dst, int h, int w, int wb,
+                                                         int slice, int D4, long total) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int c = (int)(i % D4);
+        const long rowi = i / D4;
+        const int e = (int)(rowi % slice);
+        const long n = rowi / slice;
+        const int blk = e >> 5, off = e & 31;
+        const int by = blk / wb, bx = blk - by * wb;
+        const int y = (by << 2) + (off >> 3), x = (bx << 3) + (off & 7);
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (y < h && x < w) v = reinterpret_cast<const float4*>(src)[(n * h * w + (long)y * w + x) * D4 + c];
+        reinterpret_cast<float4*>(dst)[i] = v;
     }
 }
 
@@ -111,7 +137,8 @@ constexpr int kMaxWin = 10;   // 2r+2 with r <= 4
 
 struct LookupArgs {
     const float* pyr[kMaxLevels];
-    int hl[kMaxLevels], wl[kMaxLevels];
+    int hl[kMaxLevels], wl[kMaxLevels], wb[kMaxLevels];
+    long slice[kMaxLevels];
     const float* coords;   // [M][2] (x, y)
     float* out;
     int ldo;
@@ -119,94 +146,167 @@ struct LookupArgs {
     int levels, r;
 };
 
-// LEVELS / RADIUS are compile-time so that the tap loop is fully unrolled: all ceil(L*(2r+2)^2/64) gather
-// loads of a wavefront are in flight together (with run-time bounds the loop serialised 7 HBM round trips
-// behind integer divisions: 18 us per pixel, 16 % of HBM peak).  LEVELS = 0 selects the generic fallback.
-template <int LEVELS, int RADIUS>
-__global__ __launch_bounds__(256) void corr_lookup_kernel(const LookupArgs a) {
+// any (levels, radius): one tap per lane per trip.  The reference configuration (4 levels, radius 4) takes the block
+// kernel below.
+__global__ __launch_bounds__(256) void corr_lookup_generic_kernel(const LookupArgs a) {
     __shared__ float win[4][kMaxLevels * kMaxWin * kMaxWin];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const long m = (long)blockIdx.x * 4 + wave;
-    const bool live = m < a.M;
-    const int levels = LEVELS ? LEVELS : a.levels;
-    const int r = LEVELS ? RADIUS : a.r;
+    if (m >= a.M) return;                                       // no workgroup barrier below
+    const int levels = a.levels, r = a.r;
     const int rd = 2 * r + 1, wn = rd + 1, wn2 = wn * wn;
-    float cx = 0.f, cy = 0.f;
-    if (live) {
-        const float2 c = reinterpret_cast<const float2*>(a.coords)[m];
-        cx = c.x;
-        cy = c.y;
-    }
+    const float2 c = reinterpret_cast<const float2*>(a.coords)[m];
     float* s = win[wave];
-    constexpr int kRounds = LEVELS ? (LEVELS * (2 * RADIUS + 2) * (2 * RADIUS + 2) + 63) / 64 : 0;
-    if (LEVELS) {
-        float vals[kRounds ? kRounds : 1];
-#pragma unroll
-        for (int q = 0; q < kRounds; ++q) {
-            const int t = q * 64 + lane;
-            const int l = t / wn2;                       // compile-time divisors
-            const int rem = t - l * wn2;
-            const int ty = rem / wn, tx = rem - ty * wn;
-            const float inv = 1.0f / (float)(1 << l);    // exact: coords / 2**l
-            const float xs = cx * inv, ys = cy * inv;
-            float v = 0.f;
-            if (live && t < LEVELS * wn2 && fabsf(xs) < 1.0e7f && fabsf(ys) < 1.0e7f) {
-                const int xx = (int)floorf(xs) - r + tx;
-                const int yy = (int)floorf(ys) - r + ty;
-                const int hl = a.hl[l], wl = a.wl[l];
-                if ((unsigned)xx < (unsigned)wl && (unsigned)yy < (unsigned)hl)
-                    v = a.pyr[l][m * (long)hl * wl + (long)yy * wl + xx];
-            }
-            vals[q] = v;
+    for (int t = lane; t < levels * wn2; t += 64) {
+        const int l = t / wn2;
+        const int rem = t - l * wn2;
+        const int ty = rem / wn, tx = rem - ty * wn;
+        const float inv = 1.0f / (float)(1 << l);               // exact: coords / 2**l
+        const float xs = c.x * inv, ys = c.y * inv;
+        float v = 0.f;
+        if (fabsf(xs) < 1.0e7f && fabsf(ys) < 1.0e7f) {
+            const int xx = (int)floorf(xs) - r + tx;
+            const int yy = (int)floorf(ys) - r + ty;
+            if ((unsigned)xx < (unsigned)a.wl[l] && (unsigned)yy < (unsigned)a.hl[l])
+                v = a.pyr[l][m * a.slice[l] + blocked_index(yy, xx, a.wb[l])];
         }
-#pragma unroll
-        for (int q = 0; q < kRounds; ++q) {
-            const int t = q * 64 + lane;
-            if (t < LEVELS * wn2) s[t] = vals[q];
-        }
-    } else if (live) {
-        for (int t = lane; t < levels * wn2; t += 64) {
-            const int l = t / wn2;
-            const int rem = t - l * wn2;
-            const int ty = rem / wn, tx = rem - ty * wn;
-            const float inv = 1.0f / (float)(1 << l);
-            const float xs = cx * inv, ys = cy * inv;
-            float v = 0.f;
-            if (fabsf(xs) < 1.0e7f && fabsf(ys) < 1.0e7f) {
-                const int xx = (int)floorf(xs) - r + tx;
-                const int yy = (int)floorf(ys) - r + ty;
-                if ((unsigned)xx < (unsigned)a.wl[l] && (unsigned)yy < (unsigned)a.hl[l])
-                    v = a.pyr[l][m * (long)a.hl[l] * a.wl[l] + (long)yy * a.wl[l] + xx];
-            }
-            s[t] = v;
-        }
+        s[t] = v;
     }
-    // each wavefront owns its LDS window (win[wave]): LDS operations of one wave complete in order, so a
-    // wave-level fence is enough and the four pixels of a workgroup never wait for each other
+    // each wavefront owns its LDS window (win[wave]): LDS operations of one wave complete in order
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    if (!live) return;
     float* o = a.out + m * (long)a.ldo;
     const int rd2 = rd * rd;
-    const int nout = levels * rd2;
-    constexpr int kOutRounds = LEVELS ? (LEVELS * (2 * RADIUS + 1) * (2 * RADIUS + 1) + 63) / 64 : 1;
+    for (int k = lane; k < levels * rd2; k += 64) {
+        const int l = k / rd2;
+        const int rem = k - l * rd2;
+        const int i = rem / rd, j = rem - i * rd;               // i: x offset (slow), j: y offset (fast)
+        const float inv = 1.0f / (float)(1 << l);
+        const float xs = c.x * inv, ys = c.y * inv;
+        const float fx = xs - floorf(xs), fy = ys - floorf(ys);
+        const float* b = s + l * wn2 + j * wn + i;
+        float acc = b[0] * ((1.f - fx) * (1.f - fy));
+        acc = acc + b[1] * (fx * (1.f - fy));
+        acc = acc + b[wn] * ((1.f - fx) * fy);
+        acc = acc + b[wn + 1] * (fx * fy);
+        o[k] = acc;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// lookup on the BLOCKED pyramid.  HBM hands data over in 128-byte lines (profiles/r02_pmc_calibration.txt: a gather of
+// 40-byte rows moves 4.1x its bytes), so a 10x10 window of a row-major slice costs ten lines per level for 400 useful
+// bytes.  In the blocked layout a slice is stored as 4-row x 8-column blocks of 128 bytes = one line each; a window
+// then touches (10+3)/4 x (10+7)/8 = 6.9 lines on average instead of 13, every one of them fetched with eight dense
+// 16-byte lane loads, all 4 levels (48 block slots) in six rounds that are in flight together.
+// ------------------------------------------------------------------------------------------
+struct LookupBArgs {
+    const float* pyr[kMaxLevels];
+    int hb[kMaxLevels], wb[kMaxLevels];     // blocks per slice column / row
+    long slice[kMaxLevels];                 // floats per pixel slice = hb * wb * 32
+    const float* coords;
+    float* out;
+    int ldo;
+    long M;
+};
+
+constexpr int kWinRows = 16, kWinCols = 24;   // 4 x 3 block slots per level
+
+// The row-major kernel above turned out VALU-bound, not HBM-bound: ~490 vector instructions per pixel (35 of them
+// quarter-rate 32-bit multiplies, 64-bit address arithmetic per tap) = 310 us of VALU time per 64-pair launch.  Here a
+// wavefront walks pixels m, m + stride, ...; everything that does not depend on the pixel (which block slot and which
+// 16-byte piece a lane fetches, where it lands in the LDS window, which output channel a lane owns) is computed once
+// per wavefront, the pixel index and slice bases live in scalar registers, taps come through buffer descriptors whose
+// range check turns an invalid block into zeros (one v_cndmask instead of a branch), and every round has a compile-time
+// pyramid level: two rounds of block loads (12 slots x 8 pieces) and two rounds of outputs (81 channels) per level.
+typedef int v4i __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(256) void corr_lookup_blocked_kernel(const LookupBArgs a) {
+    __shared__ __attribute__((aligned(16))) float win[4][2 * kWinRows * kWinCols];
+    constexpr int r = 4, rd = 9, kLvl = kWinRows * kWinCols;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float* s = win[wave];
+    // ---- per-lane constants
+    const int part = lane & 7;
+    int bj[2], bi[2], lds_off[2];
+    bool slot_ok[2];
 #pragma unroll
-    for (int q = 0; q < (LEVELS ? kOutRounds : 1); ++q) {
-        for (int k = q * 64 + lane; k < (LEVELS ? min(nout, (q + 1) * 64) : nout); k += 64) {
-            const int l = k / rd2;
-            const int rem = k - l * rd2;
-            const int i = rem / rd, j = rem - i * rd;   // i: x offset (slow), j: y offset (fast)
-            const float inv = 1.0f / (float)(1 << l);
-            const float xs = cx * inv, ys = cy * inv;
-            const float fx = xs - floorf(xs), fy = ys - floorf(ys);
-            const float* b = s + l * wn2 + j * wn + i;
-            const float v00 = b[0], v01 = b[1], v10 = b[wn], v11 = b[wn + 1];
-            float acc = v00 * ((1.f - fx) * (1.f - fy));
-            acc = acc + v01 * (fx * (1.f - fy));
-            acc = acc + v10 * ((1.f - fx) * fy);
-            acc = acc + v11 * (fx * fy);
-            o[k] = acc;
+    for (int rr = 0; rr < 2; ++rr) {
+        const int slot = rr * 8 + (lane >> 3);                  // 0..15, 12 used: slot = bj * 3 + bi
+        slot_ok[rr] = slot < 12;
+        bj[rr] = (slot * 11) >> 5;                              // slot / 3 for slot < 16
+        bi[rr] = slot - 3 * bj[rr];
+        lds_off[rr] = (bj[rr] * 4 + (part >> 1)) * kWinCols + bi[rr] * 8 + ((part & 1) << 2);
+    }
+    int tap_off[2];
+#pragma unroll
+    for (int rr = 0; rr < 2; ++rr) {
+        const int k = min(rr * 64 + lane, rd * rd - 1);
+        const int i = (k * 57) >> 9;                            // k / 9 for k < 81
+        tap_off[rr] = (k - 9 * i) * kWinCols + i;               // i: x offset (slow), j: y offset (fast)
+    }
+    const long stride = (long)gridDim.x * 4;
+    for (long mm = (long)blockIdx.x * 4 + wave; mm < a.M; mm += stride) {
+        const unsigned m_lo = __builtin_amdgcn_readfirstlane((unsigned)mm), m_hi = __builtin_amdgcn_readfirstlane((unsigned)(mm >> 32));
+        const long m = (long)(((unsigned long long)m_hi << 32) | m_lo);     // wave-uniform: addressing on the scalar unit
+        const float2 c = reinterpret_cast<const float2*>(a.coords)[m];
+        int wx[4], wy[4];
+        float w00[4], w01[4], w10[4], w11[4];
+        v4i v[8];
+#pragma unroll
+        for (int l = 0; l < 4; ++l) {
+            const float inv = 1.0f / (float)(1 << l);           // exact: coords / 2**l
+            const float xs = c.x * inv, ys = c.y * inv;
+            const bool sane = fabsf(xs) < 1.0e7f && fabsf(ys) < 1.0e7f;
+            const float xf = floorf(xs), yf = floorf(ys);
+            const float fx = xs - xf, fy = ys - yf;
+            w00[l] = (1.f - fx) * (1.f - fy);
+            w01[l] = fx * (1.f - fy);
+            w10[l] = (1.f - fx) * fy;
+            w11[l] = fx * fy;
+            wx[l] = sane ? (int)xf - r : -100000;
+            wy[l] = sane ? (int)yf - r : -100000;
+            const __amdgpu_buffer_rsrc_t rs =
+                __builtin_amdgcn_make_buffer_rsrc((void*)(a.pyr[l] + m * a.slice[l]), (short)0, (int)(a.slice[l] * 4), 0x00020000);
+#pragma unroll
+            for (int rr = 0; rr < 2; ++rr) {
+                const int by = (wy[l] >> 2) + bj[rr], bx = (wx[l] >> 3) + bi[rr];
+                const bool ok = slot_ok[rr] && (unsigned)by < (unsigned)a.hb[l] && (unsigned)bx < (unsigned)a.wb[l];
+                const int voff = ((__mul24(by, a.wb[l]) + bx) << 7) + (part << 4);
+                v[l * 2 + rr] = __builtin_amdgcn_raw_buffer_load_b128(rs, ok ? voff : -1, 0, 0);   // out of range -> zeros
+            }
+        }
+        float* o = a.out + m * (long)a.ldo;
+        // all eight block loads are in flight; the window holds two levels at a time (3 KB per wavefront keeps eight
+        // wavefronts per SIMD resident)
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+#pragma unroll
+            for (int l2 = 0; l2 < 2; ++l2)
+#pragma unroll
+                for (int rr = 0; rr < 2; ++rr)
+                    if (slot_ok[rr]) *reinterpret_cast<v4i*>(s + l2 * kLvl + lds_off[rr]) = v[(half * 2 + l2) * 2 + rr];
+            // each wavefront owns its LDS window: LDS operations of one wave complete in order
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+            for (int l2 = 0; l2 < 2; ++l2) {
+                const int l = half * 2 + l2;
+                const float* sl = s + l2 * kLvl + (wy[l] & 3) * kWinCols + (wx[l] & 7);
+#pragma unroll
+                for (int rr = 0; rr < 2; ++rr) {
+                    const float* b = sl + tap_off[rr];
+                    const float v00 = b[0], v01 = b[1], v10 = b[kWinCols], v11 = b[kWinCols + 1];
+                    float acc = v00 * w00[l];
+                    acc = acc + v01 * w01[l];
+                    acc = acc + v10 * w10[l];
+                    acc = acc + v11 * w11[l];
+                    if (rr == 0 || lane < rd * rd - 64) o[l * (rd * rd) + rr * 64 + lane] = acc;
+                }
+            }
+            __builtin_amdgcn_wave_barrier();                   // the window is rewritten next
         }
     }
 }
@@ -414,20 +514,40 @@ int ofx_local_corr_launch(const float* f1, const float* f2, const float* coords,
     return ofx_launch_status();
 }
 
+int ofx_corr_slice_floats_l(int hl, int wl) { return ((hl + 3) >> 2) * ((wl + 7) >> 3) * 32; }
+
 int ofx_corr_pool_launch(const float* l0, float* l1, float* l2, float* l3, int B, int h, int w, int levels, hipStream_t s) {
     PoolArgs a{};
-    a.l0 = l0; a.l1 = l1; a.l2 = l2; a.l3 = l3;
-    a.h0 = h; a.w0 = w; a.h1 = h / 2; a.w1 = w / 2; a.h2 = h / 4; a.w2 = w / 4; a.h3 = h / 8; a.w3 = w / 8;
+    a.l0 = l0; a.lv[1] = l1; a.lv[2] = l2; a.lv[3] = l3;
+    for (int l = 0; l < 4; ++l) {
+        a.h[l] = h >> l; a.w[l] = w >> l;
+        a.wb[l] = ((w >> l) + 7) >> 3;
+        a.slice[l] = ofx_corr_slice_floats_l(h >> l, w >> l);
+    }
     a.levels = levels;
-    OFX_REQUIRE(a.h1 > 0 && a.w1 > 0, OFX_EINVAL);
-    const size_t lds = sizeof(float) * ((size_t)a.h1 * a.w1 + (size_t)a.h2 * a.w2);
+    OFX_REQUIRE(a.h[1] > 0 && a.w[1] > 0, OFX_EINVAL);
+    const size_t lds = sizeof(float) * ((size_t)a.h[1] * a.w[1] + (size_t)a.h[2] * a.w[2] + (size_t)a.h[3] * a.w[3]);
     OFX_REQUIRE(lds <= 64 * 1024, OFX_EINVAL);
     OfxProfScope prof("corr_pyramid_pool", s);
     hipLaunchKernelGGL(pyramid_pool_kernel, dim3((unsigned)((long)B * h * w)), dim3(256), lds, s, a);
     return ofx_launch_status();
 }
 
+// src [n][h*w][D] (pixel order) -> dst [n][slice][D] (blocked order, zero rows for padding); D % 4 == 0
+int ofx_corr_block_rows(const float* src, float* dst, int n, int h, int w, int D, hipStream_t s) {
+    OFX_REQUIRE(src && dst && n > 0 && h > 0 && w > 0 && D > 0 && (D & 3) == 0, OFX_EINVAL);
+    OFX_REQUIRE(ofx_aligned16(src) && ofx_aligned16(dst), OFX_EALIGN);
+    const int slice = ofx_corr_slice_floats_l(h, w);
+    const long total = (long)n * slice * (D >> 2);
+    OfxProfScope prof("corr_block_rows", s);
+    hipLaunchKernelGGL(block_rows_kernel, dim3((unsigned)std::min<long>((total + 255) / 256, 256L * 64)), dim3(256), 0, s, src, dst, h, w,
+                       (w + 7) >> 3, slice, D >> 2, total);
+    return ofx_launch_status();
+}
+
 extern "C" {
+
+int ofx_corr_slice_floats(int h_l, int w_l) { return (h_l > 0 && w_l > 0) ? ofx_corr_slice_floats_l(h_l, w_l) : 0; }
 
 int ofx_corr_volume(const float* f1, const float* f2, float* const* pyr, int B, int h, int w, int D, int levels,
                     void* stream) {
@@ -435,19 +555,28 @@ int ofx_corr_volume(const float* f1, const float* f2, float* const* pyr, int B, 
     OFX_REQUIRE(levels >= 1 && levels <= kMaxLevels, OFX_EINVAL);
     OFX_REQUIRE(D % 32 == 0, OFX_EALIGN);
     for (int l = 0; l < levels; ++l) OFX_REQUIRE(pyr[l] != nullptr, OFX_EINVAL);
-    const int N = h * w;
-    // level 0: batched GEMM  vol[b] = f1[b] (N x D) * f2[b]^T (D x N) / sqrt(D)
-    ofx_conv_desc d{};
-    d.in0 = f1; d.ld0 = D; d.c0 = D;
-    d.w = f2;
-    d.out = pyr[0]; d.ldo = N;
-    d.nz = B; d.a_zs = (long)N * D; d.w_zs = (long)N * D; d.o_zs = (long)N * N;
-    d.B = 1; d.Hin = h; d.Win = w; d.Hout = h; d.Wout = w; d.Cout = N;
-    d.KH = 1; d.KW = 1; d.stride = 1; d.padH = 0; d.padW = 0;
-    d.act = OFX_ACT_NONE; d.epi = OFX_EPI_PLAIN;
+    const long N = (long)h * w;
+    const long Nb = ofx_corr_slice_floats_l(h, w);
     hipStream_t s = (hipStream_t)stream;
-    int st = ofx_conv2d_alpha(&d, 1.0f / sqrtf((float)D), stream);   // D = 256 -> exactly /16
+    // the GEMM's B operand in blocked row order (stream-ordered scratch: freed behind the GEMM on the same stream)
+    float* f2b = nullptr;
+    OFX_HIP_CHECK(hipMallocAsync((void**)&f2b, (size_t)B * Nb * D * sizeof(float), s));
+    int st = ofx_corr_block_rows(f2, f2b, B, h, w, D, s);
+    if (!st) {
+        // level 0: batched GEMM  vol[b] = f1[b] (N x D) * f2b[b]^T (D x Nb) / sqrt(D)
+        ofx_conv_desc d{};
+        d.in0 = f1; d.ld0 = D; d.c0 = D;
+        d.w = f2b;
+        d.out = pyr[0]; d.ldo = (int)Nb;
+        d.nz = B; d.a_zs = N * D; d.w_zs = Nb * D; d.o_zs = N * Nb;
+        d.B = 1; d.Hin = h; d.Win = w; d.Hout = h; d.Wout = w; d.Cout = (int)Nb;
+        d.KH = 1; d.KW = 1; d.stride = 1; d.padH = 0; d.padW = 0;
+        d.act = OFX_ACT_NONE; d.epi = OFX_EPI_PLAIN;
+        st = ofx_conv2d_alpha(&d, 1.0f / sqrtf((float)D), stream);   // D = 256 -> exactly /16
+    }
+    const hipError_t fe = hipFreeAsync(f2b, s);
     if (st) return st;
+    if (fe != hipSuccess) return (int)fe;
     if (levels == 1) return 0;
     return ofx_corr_pool_launch(pyr[0], pyr[1], levels > 2 ? pyr[2] : nullptr, levels > 3 ? pyr[3] : nullptr, B, h, w, levels, s);
 }
@@ -458,21 +587,32 @@ int ofx_corr_lookup(const float* const* pyr, const float* coords, float* out, in
     OFX_REQUIRE(levels >= 1 && levels <= kMaxLevels && radius >= 0 && 2 * radius + 2 <= kMaxWin, OFX_EINVAL);
     OFX_REQUIRE(ldo >= levels * (2 * radius + 1) * (2 * radius + 1), OFX_EINVAL);
     OFX_REQUIRE((((uintptr_t)coords) & 7u) == 0, OFX_EALIGN);
+    for (int l = 0; l < levels; ++l) OFX_REQUIRE(pyr[l] != nullptr && ofx_aligned16(pyr[l]) && (h >> l) > 0 && (w >> l) > 0, OFX_EINVAL);
+    hipStream_t s = (hipStream_t)stream;
+    const long M = (long)B * h * w;
+    OfxProfScope prof("corr_lookup", s);
+    if (levels == 4 && radius == 4 && (long)ofx_corr_slice_floats_l(h, w) * 4 < (1L << 31)) {
+        LookupBArgs a{};
+        for (int l = 0; l < 4; ++l) {
+            a.pyr[l] = pyr[l];
+            a.hb[l] = ((h >> l) + 3) >> 2;
+            a.wb[l] = ((w >> l) + 7) >> 3;
+            a.slice[l] = (long)a.hb[l] * a.wb[l] * 32;
+        }
+        a.coords = coords; a.out = out; a.ldo = ldo; a.M = M;
+        hipLaunchKernelGGL(corr_lookup_blocked_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, s, a);
+        return ofx_launch_status();
+    }
     LookupArgs a{};
     for (int l = 0; l < levels; ++l) {
-        OFX_REQUIRE(pyr[l] != nullptr, OFX_EINVAL);
         a.pyr[l] = pyr[l];
         a.hl[l] = h >> l;
         a.wl[l] = w >> l;
-        OFX_REQUIRE(a.hl[l] > 0 && a.wl[l] > 0, OFX_EINVAL);
+        a.wb[l] = ((w >> l) + 7) >> 3;
+        a.slice[l] = ofx_corr_slice_floats_l(h >> l, w >> l);
     }
-    a.coords = coords; a.out = out; a.ldo = ldo; a.M = (long)B * h * w; a.levels = levels; a.r = radius;
-    hipStream_t s = (hipStream_t)stream;
-    OfxProfScope prof("corr_lookup", s);
-    if (levels == 4 && radius == 4)
-        hipLaunchKernelGGL((corr_lookup_kernel<4, 4>), dim3((unsigned)((a.M + 3) / 4)), dim3(256), 0, s, a);
-    else
-        hipLaunchKernelGGL((corr_lookup_kernel<0, 0>), dim3((unsigned)((a.M + 3) / 4)), dim3(256), 0, s, a);
+    a.coords = coords; a.out = out; a.ldo = ldo; a.M = M; a.levels = levels; a.r = radius;
+    hipLaunchKernelGGL(corr_lookup_generic_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, s, a);
     return ofx_launch_status();
 }
 

@@ -44,6 +44,9 @@ extern "C" int ofx_conv2d_alpha(const ofx_conv_desc* d, float alpha, void* strea
 int ofx_local_corr_launch(const float* f1, const float* f2, const float* coords, float* out, long sb, long sn,
                           long sc, long sp, int B, int H1, int W1, int H2, int W2, int C, int N, int r, float scale,
                           float cscale, hipStream_t s);
+// blocked pyramid layout (corr.hip): floats per pixel slice of an hl x wl level; fmap rows -> blocked order
+int ofx_corr_slice_floats_l(int hl, int wl);
+int ofx_corr_block_rows(const float* src, float* dst, int n, int h, int w, int D, hipStream_t s);
 int ofx_corr_pool_launch(const float* l0, float* l1, float* l2, float* l3, int B, int h, int w, int levels, hipStream_t s);
 // mask_bits.hip: binary threshold/edge source -> elliptical dilation on bit planes
 enum { OFX_MSRC_CONF_LT = 0, OFX_MSRC_CONF_NGT = 1, OFX_MSRC_EDGES = 3 };   // conf < t | !(conf > t) | Laplacian edges

@@ -428,6 +428,7 @@ struct RaftWs {
     EncBufs eb[3];    // [1], [2] only exist (else alias [0]) when the encoders may run concurrently
     void* sk[3];      // split-K scratch per stream (small batches only; null otherwise)
     float *fmap1, *fmap2, *f2l[LEVELS];
+    float* fmap2b;    // image-2 feature maps with rows in the blocked order of the volume's columns (corr.hip)
     float* ctx;       // indexed-pairs mode: per-image context features [n][N][256] (tanh | relu halves)
     int* idx_dev;     // indexed-pairs mode: image1 index per pair
     float* pyr[LEVELS];
@@ -476,7 +477,8 @@ static RaftWs carve(void* base, size_t cap, int B, int H, int W, int flags, int 
         w.f2l[0] = w.fmap2;
         for (int l = 1; l < LEVELS; ++l) w.f2l[l] = c.take((size_t)n2 * (h >> l) * (wd >> l) * FD);
     } else {
-        for (int l = 0; l < LEVELS; ++l) w.pyr[l] = c.take((size_t)M * (h >> l) * (wd >> l));
+        w.fmap2b = c.take((size_t)(n_images > 0 ? n_images : n2) * ofx_corr_slice_floats_l(h, wd) * FD);
+        for (int l = 0; l < LEVELS; ++l) w.pyr[l] = c.take((size_t)M * ofx_corr_slice_floats_l(h >> l, wd >> l));
     }
     w.hx = c.take((size_t)M * HX_LD);
     w.gadd = c.take((size_t)M * GADD_LD);
@@ -704,12 +706,16 @@ int ofx_raft_forward(ofx_raft* r, const uint8_t* image1, const uint8_t* image2, 
 
     // ---- correlation
     if (!alt) {
+        // the volume's columns in blocked order: permute the rows of the B operand once (6.3 MB per image)
+        const long Nb = ofx_corr_slice_floats_l(h, w);
+        st = ofx_corr_block_rows(ws.fmap2, ws.fmap2b, (int)n2, h, w, FD, s);
+        if (st) return st;
         ofx_conv_desc d{};
         d.in0 = ws.fmap1; d.ld0 = FD; d.c0 = FD;
-        d.w = ws.fmap2;
-        d.out = ws.pyr[0]; d.ldo = (int)N;
-        d.nz = B; d.a_zs = sh1 ? 0 : N * FD; d.w_zs = sh2 ? 0 : N * FD; d.o_zs = N * N;
-        d.B = 1; d.Hin = h; d.Win = w; d.Hout = h; d.Wout = w; d.Cout = (int)N;
+        d.w = ws.fmap2b;
+        d.out = ws.pyr[0]; d.ldo = (int)Nb;
+        d.nz = B; d.a_zs = sh1 ? 0 : N * FD; d.w_zs = sh2 ? 0 : Nb * FD; d.o_zs = N * Nb;
+        d.B = 1; d.Hin = h; d.Win = w; d.Hout = h; d.Wout = w; d.Cout = (int)Nb;
         d.KH = 1; d.KW = 1; d.stride = 1;
         d.act = OFX_ACT_NONE; d.epi = OFX_EPI_PLAIN;
         d.precision = prec;
@@ -738,7 +744,7 @@ int ofx_raft_forward(ofx_raft* r, const uint8_t* image1, const uint8_t* image2, 
         for (int l = 0; l < LEVELS; ++l) {
             char nm[8];
             snprintf(nm, sizeof nm, "pyr%d", l);
-            reg(nm, ws.pyr[l], (size_t)M * (h >> l) * (w >> l));
+            reg(nm, ws.pyr[l], (size_t)M * ofx_corr_slice_floats_l(h >> l, w >> l));   // blocked layout (ofx.h)
         }
     return 0;
 }
@@ -787,12 +793,15 @@ int ofx_raft_forward_pairs(ofx_raft* r, const uint8_t* images, int n_images, con
     OFX_HIP_CHECK(hipMemcpyAsync(ws.idx_dev, idx1, sizeof(int) * B, hipMemcpyHostToDevice, s));
     st = ofx_ctx_gather(ws.ctx, ws.idx_dev, ws.hx, HX_LD, INP_OFF, HD, B, N, s);
     if (st) return st;
-    for (int b = 0; b < B && !st; ++b) {   // one N x N correlation GEMM per pair, straight from the shared feature maps
+    const long Nb = ofx_corr_slice_floats_l(h, w);
+    st = ofx_corr_block_rows(ws.fmap1, ws.fmap2b, n_images, h, w, FD, s);   // every image can be an image2: blocked copy of all
+    if (st) return st;
+    for (int b = 0; b < B && !st; ++b) {   // one N x Nb correlation GEMM per pair, straight from the shared feature maps
         ofx_conv_desc d{};
         d.in0 = ws.fmap1 + (long)idx1[b] * N * FD; d.ld0 = FD; d.c0 = FD;
-        d.w = ws.fmap1 + (long)idx2[b] * N * FD;
-        d.out = ws.pyr[0] + (long)b * N * N; d.ldo = (int)N;
-        d.B = 1; d.Hin = h; d.Win = w; d.Hout = h; d.Wout = w; d.Cout = (int)N;
+        d.w = ws.fmap2b + (long)idx2[b] * Nb * FD;
+        d.out = ws.pyr[0] + (long)b * N * Nb; d.ldo = (int)Nb;
+        d.B = 1; d.Hin = h; d.Win = w; d.Hout = h; d.Wout = w; d.Cout = (int)Nb;
         d.KH = 1; d.KW = 1; d.stride = 1;
         d.act = OFX_ACT_NONE; d.epi = OFX_EPI_PLAIN;
         d.precision = prec;

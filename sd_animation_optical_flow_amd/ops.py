@@ -308,15 +308,29 @@ def preprocess_u8(img: torch.Tensor, bgr: bool = False) -> torch.Tensor:
     return out
 
 
+def corr_slice_floats(hl: int, wl: int) -> int:
+    """Floats per pixel slice of an hl x wl pyramid level in the blocked layout (4 x 8 blocks, see include/ofx.h)."""
+    return ((hl + 3) // 4) * ((wl + 7) // 8) * 32
+
+
 def corr_volume(f1: torch.Tensor, f2: torch.Tensor, levels: int = 4) -> List[torch.Tensor]:
-    """f1, f2 f32 [B,h,w,D] (NHWC) -> pyramid list, level l: [B*h*w, h>>l, w>>l]."""
+    """f1, f2 f32 [B,h,w,D] (NHWC) -> pyramid list, level l: [B*h*w, corr_slice_floats(h>>l, w>>l)] in the blocked
+    layout `corr_lookup` reads; `corr_unblock` gives the [B*h*w, h>>l, w>>l] view of CorrBlock.corr_pyramid."""
     a = _chk(f1, "fmap1", torch.float32)
     b = _chk(f2, "fmap2", torch.float32)
     B, h, w, D = a.shape
-    pyr = [torch.empty((B * h * w, h >> l, w >> l), dtype=torch.float32, device=a.device) for l in range(levels)]
+    pyr = [torch.empty((B * h * w, corr_slice_floats(h >> l, w >> l)), dtype=torch.float32, device=a.device) for l in range(levels)]
     arr = (C.c_void_p * levels)(*[p.data_ptr() for p in pyr])
     check(_lib.lib().ofx_corr_volume(_ptr(a), _ptr(b), arr, B, h, w, D, levels, _stream()), "ofx_corr_volume")
     return pyr
+
+
+def corr_unblock(p: torch.Tensor, hl: int, wl: int) -> torch.Tensor:
+    """Blocked slices [M, corr_slice_floats(hl, wl)] (or a flat buffer) -> row-major [M, hl, wl] (pure indexing: for
+    tests and inspection, not on any hot path)."""
+    hb, wb = (hl + 3) // 4, (wl + 7) // 8
+    q = p.reshape(-1, hb, wb, 4, 8).permute(0, 1, 3, 2, 4).reshape(-1, hb * 4, wb * 8)
+    return q[:, :hl, :wl].contiguous()
 
 
 def corr_lookup(pyr: Sequence[torch.Tensor], coords: torch.Tensor, B: int, h: int, w: int, radius: int = 4) -> torch.Tensor:

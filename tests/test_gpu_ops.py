@@ -208,7 +208,12 @@ def test_corr_volume_pyramid_and_lookup(cuda, shape):
     ref_pyr = RO.corr_pyramid(f1, f2)
     pyr = ops.corr_volume(nhwc(f1), nhwc(f2))
     for l in range(4):
-        err = (pyr[l].cpu() - ref_pyr[l][:, 0]).abs().max().item()
+        hl, wl = h >> l, w >> l
+        assert tuple(pyr[l].shape) == (B * h * w, ops.corr_slice_floats(hl, wl))
+        got = ops.corr_unblock(pyr[l], hl, wl).cpu()                     # blocked 4x8 layout -> [M, hl, wl]
+        err = (got - ref_pyr[l][:, 0]).abs().max().item()
+        # padding elements of the blocked slices are zero (the lookup relies on it)
+        assert abs(float(pyr[l].double().abs().sum()) - float(got.double().abs().sum())) <= 1e-6 * max(1.0, float(got.double().abs().sum()))
         assert err < 3e-5, (l, err)
     # lookups: integer, fractional and far out-of-range coordinates
     coords = RO.coords_grid(B, h, w)
@@ -501,10 +506,10 @@ def test_corr_volume_beyond_2gib_is_split_along_m(cuda):
     pyr = ops.corr_volume(f1, f2)
     rows = torch.tensor([0, 1, 12345, 20735, 20736, 20737, 25599], device="cuda")
     ref = (f1.view(-1, 256)[rows].double() @ f2.view(-1, 256).double().T / 16.0).float()
-    got = pyr[0].view(h * w, h * w)[rows]
+    got = ops.corr_unblock(pyr[0], h, w).view(h * w, h * w)[rows]
     assert (got - ref).abs().max().item() < 3e-5
     ref1 = torch.nn.functional.avg_pool2d(ref.view(len(rows), 1, h, w), 2)[:, 0]
-    assert (pyr[1][rows] - ref1).abs().max().item() < 3e-5
+    assert (ops.corr_unblock(pyr[1], h // 2, w // 2)[rows] - ref1).abs().max().item() < 3e-5
     assert torch.isfinite(pyr[3]).all()
 
 
@@ -615,3 +620,20 @@ def test_warp_bilinear_shared_keyframe_fast_path(cuda, H, W, B):
             if b == 3:
                 d2[2, 2] = 0
             assert d2.max() <= 1 and (d2 > 0).mean() < 2e-3
+
+
+def test_corr_lookup_generic_levels_and_radius(cuda):
+    """Anything but the reference's (4 levels, radius 4) takes the one-tap-per-lane kernel on the same blocked pyramid:
+    2 and 3 levels, radii 1..3, frame sizes that are not multiples of the 4x8 block, against the oracle."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(9)
+    for (B, h, w, levels, radius) in ((1, 13, 19, 3, 2), (2, 8, 24, 2, 3), (1, 21, 9, 4, 1)):
+        f1 = torch.randn((B, 64, h, w), generator=g)
+        f2 = torch.randn((B, 64, h, w), generator=g)
+        ref_pyr = RO.corr_pyramid(f1, f2, levels)
+        pyr = ops.corr_volume(nhwc(f1), nhwc(f2), levels)
+        c = RO.coords_grid(B, h, w) + (torch.rand((B, 2, h, w), generator=g) - 0.5) * 9
+        ref = RO.corr_lookup(ref_pyr, c, radius)
+        out = ops.corr_lookup(pyr, nhwc(c), B, h, w, radius)
+        assert tuple(out.shape) == (B, h, w, levels * (2 * radius + 1) ** 2)
+        assert (nchw(out) - ref).abs().max().item() < 1e-4, (B, h, w, levels, radius)

@@ -61,8 +61,9 @@ def test_stage_parity_one_iteration(engine, raft_sd):
     fm2 = engine.buffer("fmap2").cpu()
     assert (fm2 - nhwc(tr["fmap2"])).abs().max().item() < 2e-4
     for l in range(4):
-        p = engine.buffer(f"pyr{l}").cpu()
-        assert (p - tr["pyramid"][l].reshape(-1)).abs().max().item() < 5e-4, l
+        from sd_animation_optical_flow_amd import ops
+        p = ops.corr_unblock(engine.buffer(f"pyr{l}"), h >> l, w >> l).cpu()      # 4x8-blocked slices -> [M, h_l, w_l]
+        assert (p.reshape(-1) - tr["pyramid"][l].reshape(-1)).abs().max().item() < 5e-4, l
     hx = engine.buffer("hx").cpu().reshape(B * h * w, 384)
     # hx row layout: [h(128) | motion(126) flow(2) | inp(128)]
     assert (hx[:, 256:384] - tr["inp"].permute(0, 2, 3, 1).reshape(-1, 128)).abs().max().item() < 2e-4
@@ -223,7 +224,8 @@ def test_engine_against_the_reference_raft_vectors_directly(engine, raft_sd):
     fm1 = engine.buffer("fmap1").cpu().reshape(1, 16, 20, 256).permute(0, 3, 1, 2)
     ref_fm1 = torch.from_numpy(g["fmap1_f16"].astype(np.float32))
     assert (fm1 - ref_fm1).abs().max().item() < 2e-3 * max(1.0, ref_fm1.abs().max().item())
-    p3 = engine.buffer("pyr3").cpu().reshape(-1)
+    from sd_animation_optical_flow_amd import ops
+    p3 = ops.corr_unblock(engine.buffer("pyr3"), 2, 2).cpu().reshape(-1)
     assert (p3 - torch.from_numpy(g["pyr3"]).reshape(-1)).abs().max().item() < 5e-4
 
 
