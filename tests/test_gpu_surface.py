@@ -243,7 +243,9 @@ def test_full_hd_frame_single_pair(cuda, raft_sd):
     f2 = eng.buffer("fmap2").view(N, 256)
     rows = torch.tensor([0, 777, 16383, 16384, N - 1], device="cuda")
     ref = (f1[rows].double() @ f2.double().T / 16.0).float()
-    got = eng.buffer("pyr0").view(N, N)[rows]
+    from sd_animation_optical_flow_amd import ops
+    slices = eng.buffer("pyr0").view(N, ops.corr_slice_floats(135, 240))[rows]          # 4x8-blocked, 34 x 30 blocks per slice
+    got = ops.corr_unblock(slices, 135, 240).reshape(len(rows), N)
     assert (got - ref).abs().max().item() < 1e-4 * max(1.0, ref.abs().max().item())
 
 
