@@ -834,6 +834,7 @@ extern "C" int ofx_conv2d_alpha(const ofx_conv_desc* d, float alpha, void* strea
         if (bm == 64 && bn == 64) return wsplit ? launch_tile<64, 64, 32, 32, 16, 2>(k, d->epi, norm, nz, s) : launch_tile<64, 64, 32, 32, 16, 1>(k, d->epi, norm, nz, s);
         return OFX_EINVAL;
     }
+    if (bm == 256 && bn == 64) return launch_tile<256, 64, 64, 64, 16>(k, d->epi, norm, nz, s);
     if (bm == 128 && bn == 192) return launch_tile<128, 192, 64, 96, 16>(k, d->epi, norm, nz, s);
     if (bm == 128 && bn == 96) return launch_tile<128, 96, 32, 96, 16>(k, d->epi, norm, nz, s);
     if (bm == 128 && bn == 128 && bk == 16) return launch_tile<128, 128, 64, 64, 16>(k, d->epi, norm, nz, s);

@@ -17,6 +17,13 @@ SHAPES = [  # name, B, H, W, Cin, Cout, kh, kw, stride, tile
 TILES = [0, 128128, 16128128, 128064, 16128064, 64064, 16064064]
 if os.environ.get('CONV_BENCH_TILES'):
     TILES = [int(t) for t in os.environ['CONV_BENCH_TILES'].split(',')]
+if os.environ.get("CONV_BENCH_N64"):
+    SHAPES = [
+        ("enc 3x3 64->64 @1/2", 64, 384, 256, 64, 64, 3, 3, 1, 0),
+        ("enc 7x7 4->64 s2", 64, 768, 512, 4, 64, 7, 7, 2, 0),
+        ("3x3 128->64", 64, 96, 64, 128, 64, 3, 3, 1, 0),
+    ]
+    TILES = [0, 16128064, 16256064]
 if os.environ.get("CONV_BENCH_B1"):
     SHAPES = [
         ("b1 gru 1x5 256->256", 1, 96, 64, 256, 256, 1, 5, 1, 0),
