@@ -18,6 +18,8 @@
  *   ofx_warp_*                  pdcnet_of.py:34-42 ; ofgen_keyframe_inpaint.py:92-98 (cv2.remap)
  *   ofx_generate_mask, ofx_dilate_u8, ofx_expand_mask, ofx_travel_distance, ofx_merge_images,
  *   ofx_mix_frames, ofx_conf_sum
+ *   ofx_groupnorm, ofx_softmax_rows, ofx_attention_f32
+ *                               ldm/modules/diffusionmodules/model.py:35-41,152-203 ; ldm/modules/attention.py:314,426
  *                               ofgen_keyframe_inpaint.py:113-133,237-248,306-322,676-688,968-973,995-1027
  *
  * Layout conventions: images and flow are HWC ("channels-last"); network activations are
@@ -133,6 +135,25 @@ int ofx_resize_bicubic_u8(const uint8_t* in, uint8_t* out, uint8_t* scratch, int
 int ofx_sd_handoff(const uint8_t* image_bgr, const uint8_t* reference_bgr, const uint8_t* image_mask,
                    const uint8_t* mask_latent, float* image, float* cond_image, float* cond_mask, float* latmask,
                    float* cond_mask_latent, int B, int H, int W, int h, int w, void* stream);
+
+/* GroupNorm(groups, C, eps, affine) of an NHWC fp32 tensor [B,HW,C] (ldm/modules/diffusionmodules/model.py:40-41,
+ * `Normalize` = 32 groups, eps 1e-6), optionally followed by x * sigmoid(x) (`nonlinearity`, :35-37): the pair in front
+ * of every convolution of the VAE encoder.  gamma / beta: [C] or NULL.  Statistics in f64.  out may alias x.
+ * scratch: ofx_groupnorm_scratch_bytes(B, C) bytes, 16-byte aligned. */
+size_t ofx_groupnorm_scratch_bytes(int B, int C);
+int ofx_groupnorm(const float* x, const float* gamma, const float* beta, float* out, void* scratch, size_t scratch_bytes,
+                  int B, long HW, int C, int groups, float eps, int silu, void* stream);
+/* in place: x[r][0..n) = softmax(x[r][0..n) * scale + bias[r % bias_rows][0..n)); columns n..ld-1 are set to 0 */
+int ofx_softmax_rows(float* x, long rows, long ld, int n, float scale, const float* bias, long ld_bias, long bias_rows,
+                     void* stream);
+/* out[z] = softmax(q[z] k[z]^T * scale + bias) v[z] for z < BH; q [BH,Nq,D], k/v [BH,Nk,D], out [BH,Nq,D], fp32, D % 4 == 0.
+ * The semantics of xformers.ops.memory_efficient_attention(q, k, v, attn_bias) (ldm/modules/attention.py:314,426) and of
+ * AttnBlock.forward (model.py:179-203, BH = batch, D = channels).  bias: NULL, [Nq,Nk] shared by every z
+ * (bias_bstride = 0) or [BH,Nq,Nk] (bias_bstride = Nq*Nk).  Unfused: both GEMMs on the fp32 matrix cores, the score matrix
+ * in the workspace (ofx_attention_workspace_bytes, 16-byte aligned; slice BH to bound it). */
+size_t ofx_attention_workspace_bytes(int BH, int Nq, int Nk, int D);
+int ofx_attention_f32(const float* q, const float* k, const float* v, const float* bias, long bias_bstride, float* out,
+                      int BH, int Nq, int Nk, int D, float scale, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---------------------------------------------------------------- key-frame detector */
 /* edges[b] = cv2.dilate(cv2.Canny(V, low, high), ones(ksize, ksize)) for BGR frames u8[B,H,W,3], with V = max(B,G,R)

@@ -82,6 +82,11 @@ SIGNATURES = {
     "ofx_inorm_stats": (_i, [_p, _i, _p, _p, _p, _i, _l, _i, _f, _p]),
     "ofx_inorm_apply": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _l, _i, _i, _p]),
     "ofx_preprocess_u8": (_i, [_p, _p, _l, _i, _p]),
+    "ofx_groupnorm_scratch_bytes": (C.c_size_t, [_i, _i]),
+    "ofx_groupnorm": (_i, [_p, _p, _p, _p, _p, C.c_size_t, _i, C.c_long, _i, _i, C.c_float, _i, _p]),
+    "ofx_softmax_rows": (_i, [_p, C.c_long, C.c_long, _i, C.c_float, _p, C.c_long, C.c_long, _p]),
+    "ofx_attention_workspace_bytes": (C.c_size_t, [_i, _i, _i, _i]),
+    "ofx_attention_f32": (_i, [_p, _p, _p, _p, C.c_long, _p, _i, _i, _i, _i, C.c_float, _p, C.c_size_t, _p]),
     "ofx_corr_slice_floats": (_i, [_i, _i]),
     "ofx_corr_volume": (_i, [_p, _p, C.POINTER(_p), _i, _i, _i, _i, _i, _p]),
     "ofx_corr_lookup": (_i, [C.POINTER(_p), _p, _p, _i, _i, _i, _i, _i, _i, _p]),

@@ -240,9 +240,13 @@ def conv2d_nhwc(x: torch.Tensor, w_packed: torch.Tensor, kh: int, kw: int, cout:
                 shift: Optional[torch.Tensor] = None, scale: Optional[torch.Tensor] = None, act: Optional[str] = None,
                 x2: Optional[torch.Tensor] = None, res: Optional[torch.Tensor] = None,
                 nmean: Optional[torch.Tensor] = None, nrstd: Optional[torch.Tensor] = None, tile: int = 0,
-                precision: str = "fp32", splitk_ws: Optional[torch.Tensor] = None) -> torch.Tensor:
+                precision: str = "fp32", splitk_ws: Optional[torch.Tensor] = None, pad: Optional[Tuple[int, int]] = None,
+                out_hw: Optional[Tuple[int, int]] = None, addend: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Plain-epilogue convolution: x [B,H,W,C0] (+ optional second channel segment x2 [B,H,W,C1]),
-    'same' padding (k//2).  Returns [B,Hout,Wout,cout]."""
+    'same' padding (k//2) unless `pad` = (top, left) is given; `out_hw` overrides the output size (taps beyond the
+    input read zeros: pad (0, 0) with out_hw = (H/2, W/2) is the VAE's F.pad(x, (0,1,0,1)) + stride-2 convolution).
+    `addend` [B,Hout,Wout,cout] is added before the activation (`res` adds after it and applies ReLU).
+    Returns [B,Hout,Wout,cout]."""
     x = _chk(x, "x", torch.float32)
     B, H, W, c0 = x.shape
     d = ConvDesc()
@@ -254,10 +258,15 @@ def conv2d_nhwc(x: torch.Tensor, w_packed: torch.Tensor, kh: int, kw: int, cout:
     d.w = wp.data_ptr()
     d.scale = 0 if scale is None else _chk(scale, "scale", torch.float32).data_ptr()
     d.shift = 0 if shift is None else _chk(shift, "shift", torch.float32).data_ptr()
-    ph, pw = kh // 2, kw // 2
-    Ho, Wo = (H + 2 * ph - kh) // stride + 1, (W + 2 * pw - kw) // stride + 1
+    ph, pw = (kh // 2, kw // 2) if pad is None else pad
+    Ho, Wo = ((H + 2 * ph - kh) // stride + 1, (W + 2 * pw - kw) // stride + 1) if out_hw is None else out_hw
     out = torch.empty((B, Ho, Wo, cout), dtype=torch.float32, device=x.device)
     d.out, d.ldo = out.data_ptr(), cout
+    if addend is not None:
+        addend = _chk(addend, "addend", torch.float32)
+        if tuple(addend.shape) != (B, Ho, Wo, cout):
+            raise RuntimeError(f"addend must be {(B, Ho, Wo, cout)}, got {tuple(addend.shape)}")
+        d.addend, d.ldadd = addend.data_ptr(), cout
     if res is not None:
         res = _chk(res, "res", torch.float32)
         d.res, d.ldres = res.data_ptr(), res.shape[-1]
@@ -441,6 +450,54 @@ def sd_handoff(image_bgr: torch.Tensor, reference_bgr: torch.Tensor, image_mask:
     check(_lib.lib().ofx_sd_handoff(_ptr(a), _ptr(r), _ptr(m), _ptr(ml), _ptr(image), _ptr(cond_image), _ptr(cond_mask), _ptr(latmask),
                                     _ptr(cml), B, H, W, h, w, _stream()), "ofx_sd_handoff")
     return image, cond_image, cond_mask, latmask, cml
+
+
+def groupnorm(x: torch.Tensor, gamma: Optional[torch.Tensor], beta: Optional[torch.Tensor], groups: int = 32, eps: float = 1e-6,
+              silu: bool = False) -> torch.Tensor:
+    """GroupNorm(groups, C, eps, affine) of an NHWC tensor [B,H,W,C] (+ x * sigmoid(x) when silu): `Normalize` /
+    `nonlinearity` of ldm/modules/diffusionmodules/model.py:35-41."""
+    t = _chk(x, "x", torch.float32)
+    B, H, W, Cn = t.shape
+    L = _lib.lib()
+    need = L.ofx_groupnorm_scratch_bytes(B, Cn)
+    scratch = torch.empty((need,), dtype=torch.uint8, device=t.device)
+    out = torch.empty_like(t)
+    g = None if gamma is None else _chk(gamma, "gamma", torch.float32)
+    b = None if beta is None else _chk(beta, "beta", torch.float32)
+    check(L.ofx_groupnorm(_ptr(t), _ptr(g), _ptr(b), _ptr(out), _ptr(scratch), need, B, H * W, Cn, int(groups), float(eps),
+                          1 if silu else 0, _stream()), "ofx_groupnorm")
+    return out
+
+
+def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, bias: Optional[torch.Tensor] = None,
+              scale: Optional[float] = None, max_workspace_bytes: int = 8 << 30) -> torch.Tensor:
+    """softmax(q k^T * scale + bias) v for fp32 [BH,Nq,D] / [BH,Nk,D] tensors; bias [Nq,Nk] (shared) or [BH,Nq,Nk].
+    scale defaults to D^-0.5.  Batch-heads are processed in slices that keep the score matrix under
+    `max_workspace_bytes`."""
+    q = _chk(q, "q", torch.float32)
+    k = _chk(k, "k", torch.float32)
+    v = _chk(v, "v", torch.float32)
+    BH, Nq, D = q.shape
+    Nk = k.shape[1]
+    if tuple(k.shape) != (BH, Nk, D) or tuple(v.shape) != (BH, Nk, D):
+        raise RuntimeError("attention: q [BH,Nq,D], k / v [BH,Nk,D] expected")
+    per_bh = bias is not None and bias.dim() == 3
+    if bias is not None:
+        bias = _chk(bias, "bias", torch.float32)
+        if tuple(bias.shape) not in ((Nq, Nk), (BH, Nq, Nk)):
+            raise RuntimeError("attention: bias must be [Nq,Nk] or [BH,Nq,Nk]")
+    scale = float(D) ** -0.5 if scale is None else float(scale)
+    L = _lib.lib()
+    one = L.ofx_attention_workspace_bytes(1, Nq, Nk, D)
+    step = max(1, min(BH, int(max_workspace_bytes // max(one, 1))))
+    ws = torch.empty((L.ofx_attention_workspace_bytes(step, Nq, Nk, D),), dtype=torch.uint8, device=q.device)
+    out = torch.empty_like(q)
+    for z0 in range(0, BH, step):
+        n = min(step, BH - z0)
+        bz = None if bias is None else (bias[z0:z0 + n] if per_bh else bias)
+        check(L.ofx_attention_f32(_ptr(q[z0:z0 + n]), _ptr(k[z0:z0 + n]), _ptr(v[z0:z0 + n]), _ptr(bz), Nq * Nk if per_bh else 0,
+                                  _ptr(out[z0:z0 + n]), n, Nq, Nk, D, scale, _ptr(ws), ws.numel(), _stream()), "ofx_attention_f32")
+    return out
 
 
 # --------------------------------------------------------------------------------------
