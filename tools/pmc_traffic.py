@@ -4,9 +4,12 @@
     python tools/pmc_traffic.py <fetch pmc_results.db> <write pmc_results.db> > profiles/rNN_pmc_traffic_b64.json
 
 Units and corrections as /opt/skills/guides/MI355X_MICROARCH.md prescribes for gfx950: both counters are in KiB;
-FETCH_SIZE reports half of the bytes of wide coalesced reads on this part (128-byte requests tallied at 64 B) and
-is doubled; WRITE_SIZE is taken as is.  Calibration in our own access pattern: the pooling kernel (reads the
-whole level-0 volume once, writes levels 1-3 once) comes out at its exact algorithmic byte count.
+FETCH_SIZE reports half of the bytes read (128-byte requests tallied at 64 B) and is doubled; WRITE_SIZE is taken as
+is.  Calibrated per access width on this pool (profiles/r02_pmc_calibration.txt, tools/pmc_calib.hip: 1 GiB of known
+traffic per launch): 1-, 4-, 8- and 16-byte-per-lane coalesced reads ALL report exactly 0.5x, every store width reports
+1.0x (byte stores 1.002x), and a gather of 40-byte rows reports 2.0x its useful bytes = 4.1x after doubling, i.e. whole
+128-byte lines.  In our own access pattern the pooling kernel (reads the whole level-0 volume once, writes levels 1-3
+once) comes out at its exact algorithmic byte count.
 bytes/launch = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 / dispatches.  Kernels are grouped into the
 families bench.py reports.
 """
@@ -17,12 +20,12 @@ import sys
 FAMILIES = [
     ("igemm_conv_all", lambda n, gy: "igemm_kernel" in n and gy <= 1),
     ("corr_volume_gemm", lambda n, gy: "igemm_kernel" in n and gy > 1),
-    ("corr_lookup", lambda n, gy: "corr_lookup_kernel" in n),
+    ("corr_lookup", lambda n, gy: "corr_lookup" in n),
     ("pyramid_pool", lambda n, gy: "pyramid_pool_kernel" in n),
     ("upsample", lambda n, gy: "upsample_kernel" in n),
     ("flow_head", lambda n, gy: "flow_head_kernel" in n),
-    ("warp", lambda n, gy: "warp_u8c3_x4_kernel" in n or "warp_kernel" in n or "warp_bilinear_u8c3_kernel" in n),
-    ("mask", lambda n, gy: "mask_bits" in n),
+    ("warp", lambda n, gy: "warp_u8c3_x4_kernel" in n or "warp_kernel" in n or "warp_bilinear" in n),
+    ("mask", lambda n, gy: "mask_bits" in n or "mask_rows" in n),
 ]
 
 
