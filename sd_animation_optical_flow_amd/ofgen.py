@@ -47,7 +47,11 @@ class namespace:
 
 
 class RAFT_2:
-    """ofgen_keyframe_inpaint.py:47-71.  `model` = checkpoint path / state_dict / 'random:<seed>'."""
+    """ofgen_keyframe_inpaint.py:47-71.  `model` = checkpoint path / state_dict / 'random:<seed>'.
+
+    One deliberate difference: the reference never calls `.eval()` on its RAFT (:47-60), so as written its context
+    encoder's BatchNorm uses per-call batch statistics; the engine folds the running statistics (canonical RAFT
+    inference, and what the golden vectors pin) -- see DESIGN.md section 2."""
 
     def __init__(self, model="../RAFT/models/raft-things.pth", device="cuda", iters: int = 20, alternate_corr: bool = False):
         self.device = torch.device(device)
