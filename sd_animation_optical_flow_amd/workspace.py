@@ -50,7 +50,10 @@ class VideoData:
     """`VideoData` of ofgen_keyframe_inpaint.py:372-481.
 
     frames: None (open an existing workspace) or an iterable of decoded BGR uint8 frames [H,W,3] of size `size`
-    (w, h); every `keep_every`-th one is kept, like the extraction loop (:399-411), up to `max_len_sec` seconds."""
+    (w, h); every `keep_every`-th one is kept, like the extraction loop (:399-411), up to `max_len_sec` seconds.
+    `num_frames` is the number of PNGs in `raw-frames/` on both paths; the reference's extraction path leaves it at the
+    LAST INDEX (`self.num_frames = ctr_valid`, :414, one less than the count its own re-open path reports, :376-381) --
+    the count is the consistent reading and the only one under which every extracted frame is reachable."""
 
     def __init__(self, frames: Optional[Iterable[np.ndarray]], size: Tuple[int, int], workspace_dir: str, keep_every: int = 1,
                  max_len_sec: int = -1, fps: float = 30.0) -> None:
