@@ -160,7 +160,7 @@ int ofx_attention_f32(const float* q, const float* k, const float* v, const floa
  * (the HSV value channel) and low/high = int((1 -/+ 1/3) * np.median(V)) clipped to [0,255]
  * (_detect_edges, ofgen_keyframe_inpaint.py:161-192).  ksize odd (estimated_kernel_size, :153-158).
  * scratch: ofx_detect_edges_scratch_bytes(B,H,W) bytes, 256-byte aligned.  The hysteresis stage iterates to
- * convergence and SYNCHRONISES the stream once per sweep.  Parity: OpenCV's algorithm restated; unpinned. */
+ * convergence and SYNCHRONISES the stream once per batch of 8 sweeps (the only blocking call of the library).  Parity: OpenCV's algorithm restated; unpinned. */
 size_t ofx_detect_edges_scratch_bytes(int B, int H, int W);
 int ofx_detect_edges(const uint8_t* frames_bgr, uint8_t* edges, void* scratch, size_t scratch_bytes, int B, int H,
                      int W, int ksize, void* stream);

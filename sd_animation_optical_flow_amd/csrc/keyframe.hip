@@ -108,11 +108,16 @@ __global__ __launch_bounds__(256) void kf_canny_map_kernel(const uint8_t* __rest
 }
 
 // One hysteresis sweep: inside a 32x32 tile (with apron) candidates touching a strong pixel become strong until the
-// tile is stable; `changed` is raised when anything moved, the host relaunches until a sweep changes nothing.
+// tile is stable; `changed` is raised when anything moved.  Sweeps are enqueued in batches: a sweep first looks at the flag
+// its predecessor left (`prev`, null for the first) and retires at once when that one changed nothing, so the host checks
+// for convergence once per batch instead of once per sweep.
 constexpr int kHT = 32;
-__global__ __launch_bounds__(256) void kf_hysteresis_kernel(uint8_t* __restrict__ map, int H, int W, int* __restrict__ changed) {
+constexpr int kSweepBatch = 8;
+__global__ __launch_bounds__(256) void kf_hysteresis_kernel(uint8_t* __restrict__ map, int H, int W, const int* __restrict__ prev,
+                                                            int* __restrict__ changed) {
     __shared__ uint8_t t[kHT + 2][kHT + 2];
     __shared__ int moved, any;
+    if (prev != nullptr && __hip_atomic_load(prev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) return;   // already converged
     const long b = blockIdx.z;
     uint8_t* M = map + b * (long)H * W;
     const int x0 = blockIdx.x * kHT, y0 = blockIdx.y * kHT;
@@ -241,12 +246,16 @@ int ofx_detect_edges(const uint8_t* frames_bgr, uint8_t* edges, void* scratch, s
         hipLaunchKernelGGL(kf_thresholds_kernel, dim3(B), dim3(64), 0, st, s.hist, s.thr, HW);
         hipLaunchKernelGGL(kf_canny_map_kernel, dim3(ofx_cdiv(W, kCW), ofx_cdiv(H, kCH), B), dim3(256), 0, st, s.lum, s.thr, s.map, H, W);
     }
-    // hysteresis: sweep until nothing changes (the check is a 4-byte copy + stream synchronisation per sweep)
-    for (int it = 0; it < 4 * (H + W); ++it) {
-        OFX_HIP_CHECK(hipMemsetAsync(s.flag, 0, sizeof(int), st));
-        hipLaunchKernelGGL(kf_hysteresis_kernel, dim3(ofx_cdiv(W, kHT), ofx_cdiv(H, kHT), B), dim3(256), 0, st, s.map, H, W, s.flag);
+    // hysteresis: sweep until nothing changes.  kSweepBatch sweeps per host check (a 4-byte copy + one stream
+    // synchronisation per batch); flags[k] = "sweep k of the batch moved something", a converged sweep leaves 0 and
+    // every later sweep of the batch retires at once
+    for (int it = 0; it < 4 * (H + W); it += kSweepBatch) {
+        OFX_HIP_CHECK(hipMemsetAsync(s.flag, 0, kSweepBatch * sizeof(int), st));
+        for (int k = 0; k < kSweepBatch; ++k)
+            hipLaunchKernelGGL(kf_hysteresis_kernel, dim3(ofx_cdiv(W, kHT), ofx_cdiv(H, kHT), B), dim3(256), 0, st, s.map, H, W,
+                               k == 0 ? (const int*)nullptr : (const int*)(s.flag + k - 1), s.flag + k);
         int host_flag = 0;
-        OFX_HIP_CHECK(hipMemcpyAsync(&host_flag, s.flag, sizeof(int), hipMemcpyDeviceToHost, st));
+        OFX_HIP_CHECK(hipMemcpyAsync(&host_flag, s.flag + kSweepBatch - 1, sizeof(int), hipMemcpyDeviceToHost, st));
         OFX_HIP_CHECK(hipStreamSynchronize(st));
         if (!host_flag) break;
     }
