@@ -1,0 +1,100 @@
+"""The hot path end to end over a workspace, device-resident: the non-generative half of the reference's
+`run_exp` / `generate_ai_frame_with_ref_warp_and_inpaint*` loop (ofgen_keyframe_inpaint.py:861-1100, 1123-1262).
+
+For a clip stored as a `workspace.VideoData`:
+
+  1. key frames             `keyframes.frame_generator` decisions (`ofx_detect_edges`, `ofx_abs_diff_sum_u8`)
+  2. for every other frame  flow against its key frame + forward-backward confidence (`PDCNetPlus.calc_batch_device`),
+                            backward warp of the AI key frame, low-confidence inpaint mask (`ofx_warp_and_mask`)
+  3. SD-inpaint inputs      Pillow-exact mask blur / composite / latent mask (`handoff.prepare_inpaint_inputs`) and,
+                            when a VAE is given, the first-stage latent (`vae.VaeEncoder`)
+
+Everything between reading a PNG and handing tensors to the diffusion model stays in HBM.  What the diffusion model does
+with them (UNet, sampler, ControlNet) is out of scope: `render` is the caller's hook for it -- by
+default the "rendered" frame is the warped AI key frame with the raw frame pasted where the mask says repaint.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import Callable, Dict, List, Optional
+
+import numpy as np
+import torch
+
+from . import handoff, keyframes, ops
+
+
+@dataclass
+class FramePacket:
+    """What the SD stage receives for one frame (all tensors on the device)."""
+    index: int
+    key_index: int
+    flow: torch.Tensor                 # f32 [H,W,2], on the frame's grid, pointing into the key frame
+    confidence: torch.Tensor           # f32 [H,W]
+    warped: torch.Tensor               # u8 [H,W,3] BGR: AI key frame warped onto this frame
+    mask: torch.Tensor                 # u8 [H,W], 255 = repaint
+    inpaint: Dict[str, torch.Tensor] = field(default_factory=dict)   # handoff.prepare_inpaint_inputs (+ "init_latent")
+
+
+def _paste_raw(pkt: FramePacket, raw_bgr: torch.Tensor) -> torch.Tensor:
+    """Default stand-in for the inpainting model: raw pixels where the mask asks for a repaint (merge_images 'naive')."""
+    return ops.merge_images(pkt.warped[None], raw_bgr[None], pkt.mask[None])[0]
+
+
+class ClipPipeline:
+    """`algo`: a `pdcnet_of.PDCNetPlus`; `vae`: optional `vae.VaeEncoder`; `render(packet, raw_bgr) -> u8 [H,W,3]` turns a
+    packet into the AI frame (default: `_paste_raw`); key frames are rendered by `render_key(raw_bgr) -> u8 [H,W,3]`
+    (default: identity).  `batch` frames share one executor call per key frame."""
+
+    def __init__(self, algo, vae=None, render: Optional[Callable] = None, render_key: Optional[Callable] = None, batch: int = 64,
+                 warp_mode: str = "bilinear", thres: float = 0.95, ksize: int = 7, mask_blur: float = 4.0):
+        self.algo, self.vae = algo, vae
+        self.render = render or _paste_raw
+        self.render_key = render_key or (lambda raw: raw)
+        self.batch, self.warp_mode, self.thres, self.ksize, self.mask_blur = int(batch), warp_mode, float(thres), int(ksize), float(mask_blur)
+        self.device = algo.device
+
+    def key_frame_flags(self, video, th: float = 8.5, keep_every: int = 1) -> List[bool]:
+        frames = (video.get_raw_frame(i) for i in range(video.num_frames))
+        return [k for _, k, _ in keyframes.frame_generator(frames, fps=getattr(video, "fps", 30.0) * keep_every, th=th,
+                                                           keep_every=keep_every, device=self.device)]
+
+    @torch.no_grad()
+    def packets(self, video, flags: List[bool]):
+        """Yields (FramePacket | None, raw_bgr tensor, index): None for key frames."""
+        n = len(flags)
+        i = 0
+        while i < n:
+            assert flags[i], "the first frame of a segment is its key frame"
+            key_raw = torch.from_numpy(video.get_raw_frame(i)).to(self.device)
+            key_ai = self.render_key(key_raw)
+            video.put_ai_frame(i, key_ai.cpu().numpy())
+            yield None, key_raw, i
+            j = i + 1
+            while j < n and not flags[j]:
+                j += 1
+            for b0 in range(i + 1, j, self.batch):
+                ids = list(range(b0, min(j, b0 + self.batch)))
+                raws = torch.from_numpy(np.stack([video.get_raw_frame(t) for t in ids])).to(self.device)
+                # source = key frame, target = frames: flow on each frame's grid pointing into the key frame (BGR in)
+                flow, conf, _ = self.algo.calc_batch_device(key_raw, raws, bgr=True)
+                warped, mask = ops.warp_and_mask(key_ai.contiguous(), flow.contiguous(), conf.contiguous(), warp_mode=self.warp_mode,
+                                                 thres=self.thres, ksize=self.ksize)
+                inp = handoff.prepare_inpaint_inputs(warped, raws, mask, mask_blur=self.mask_blur, device=self.device)
+                if self.vae is not None:
+                    inp["init_latent"] = self.vae.get_first_stage_encoding(inp["image"])
+                for k, t in enumerate(ids):
+                    per = {name: v[k] for name, v in inp.items()}
+                    yield FramePacket(t, i, flow[k], conf[k], warped[k], mask[k], per), raws[k], t
+            i = j
+
+    def run(self, video, flags: Optional[List[bool]] = None) -> List[int]:
+        """Processes the whole workspace; writes `ai-frames/{n:05d}.png`; returns the key-frame indices."""
+        flags = flags if flags is not None else self.key_frame_flags(video)
+        keys = []
+        for pkt, raw, idx in self.packets(video, flags):
+            if pkt is None:
+                keys.append(idx)
+                continue
+            video.put_ai_frame(idx, self.render(pkt, raw).cpu().numpy())
+        return keys

@@ -353,3 +353,44 @@ def test_keyframe_conv_ties_go_to_the_earliest_frame(cuda, tmp_path):
     aux = ofgen.PDCNetAux(Flat(), video.workspace_dir)
     got = ofgen.keyframe_conv(aux, str(tmp_path / "kf"), video, VideoFrameIndices.from_n(9), kernel_size=4, stride=3, dilation=1)
     assert got.indices == [0, 3, 6]
+
+
+def test_clip_pipeline_end_to_end_over_a_workspace(algo, tmp_path):
+    """The whole non-generative chain on one small clip: workspace PNGs -> key-frame decisions -> per-frame flow /
+    confidence against the segment's key frame -> warp + mask -> Pillow-exact SD-inpaint inputs -> first-stage latent;
+    every AI frame lands in `ai-frames/` and the per-frame packet agrees with the step-by-step reference-style calls."""
+    from sd_animation_optical_flow_amd import handoff, ops, pipeline
+    from sd_animation_optical_flow_amd.vae import VaeEncoder, random_vae_state_dict
+    from sd_animation_optical_flow_amd.workspace import VideoData
+    H, W = 64, 96
+    g = torch.Generator().manual_seed(123)
+    base = torch.nn.functional.avg_pool2d(torch.rand((1, 3, H + 60, W + 60), generator=g), 5, 1, 2)
+    base = ((base - base.min()) / (base.max() - base.min()) * 255).round().to(torch.uint8)[0].permute(1, 2, 0).numpy()
+    scene2 = np.ascontiguousarray(base[::-1, ::-1])                                   # a cut: new key frame
+    frames = [np.ascontiguousarray(base[30 + s:30 + s + H, 30 + 2 * s:30 + 2 * s + W]) for s in range(4)]
+    frames += [np.ascontiguousarray(scene2[20 + s:20 + s + H, 25:25 + W]) for s in range(3)]
+    video = VideoData(frames, (W, H), str(tmp_path / "ws"))
+    vae = VaeEncoder(random_vae_state_dict(0))
+    pipe = pipeline.ClipPipeline(algo, vae=vae, batch=2, warp_mode="bilinear", thres=0.9, ksize=7)
+    flags = [True, False, False, False, True, False, False]
+    seen = {}
+    for pkt, raw, idx in pipe.packets(video, flags):
+        if pkt is not None:
+            seen[idx] = pkt
+    assert sorted(seen) == [1, 2, 3, 5, 6] and seen[3].key_index == 0 and seen[5].key_index == 4
+    p = seen[2]
+    assert tuple(p.inpaint["init_latent"].shape) == (4, H // 8, W // 8) and bool(torch.isfinite(p.inpaint["init_latent"]).all())
+    # the packet equals the reference-style host calls for that frame: calc(key, frame), warp, mask
+    flow, conf, _ = algo.calc(frames[0], frames[2])
+    assert np.abs(p.flow.cpu().numpy() - flow).max() < 1e-4 and np.abs(p.confidence.cpu().numpy() - conf).max() < 1e-4
+    ref_w = WO.warp_frame(frames[0], p.flow.cpu().numpy(), mode="bilinear")
+    d = np.abs(p.warped.cpu().numpy().astype(int) - ref_w.astype(int))
+    assert d.max() <= 1 and (d > 0).mean() < 2e-3
+    ref_m, _ = MO.generate_mask(p.confidence.cpu().numpy(), conf.copy(), 0.9, 7)
+    assert np.array_equal(p.mask.cpu().numpy(), ref_m)
+    keys = pipe.run(video, flags)
+    assert keys == [0, 4] and all(video.generated(i) for i in range(7))
+    assert np.array_equal(video.get_ai_frame(4), frames[4])                           # default key render = identity
+    out2 = video.get_ai_frame(2)                                                      # default render: raw pixels where masked
+    m = p.mask.cpu().numpy() == 255
+    assert np.array_equal(out2[m], frames[2][m]) and np.array_equal(out2[~m], p.warped.cpu().numpy()[~m])
