@@ -75,15 +75,20 @@ def algorithmic_work(H, W, B, shared_key=True):
     n_enc = (B + 1) if shared_key else 2 * B          # fnet images
     conv = (n_enc + B) * encoder_flops(H, W)          # + cnet on every frame
     conv += B * (ITERS * update_flops(H, W, False) + (update_flops(H, W, True) - update_flops(H, W, False)))
-    pyr = sum((n * ((H // 8) >> l) * ((W // 8) >> l)) for l in range(4)) * 4.0
+    lvl = [n * ((H // 8) >> l) * ((W // 8) >> l) * 4.0 for l in range(4)]      # bytes of each pyramid level per pair
+    pyr = sum(lvl)
+    # level 1 leaves the volume GEMM's epilogue when it is tiled by whole 4x8 blocks (corr.hip: ofx_corr_volpool_ok);
+    # the pooling kernel then starts from level 1 instead of re-reading level 0
+    fused = (H // 8) % 8 == 0 and (W // 8) % 16 == 0
     return {
         "conv_flops": conv,
         # what the kernels actually execute: the context (`inp`) third of the six GRU convolutions is
         # loop-invariant and evaluated once per pair instead of once per iteration
         "conv_flops_executed": conv - B * (ITERS - 1) * 6 * conv_flops(n, 128, 128, 1, 5),
         "volume_flops": B * 2.0 * n * n * 256,
-        "volume_bytes": B * (n * 256 * 4.0 + n * n * 4.0) + (1 if shared_key else B) * n * 256 * 4.0,   # GEMM: read fmaps, write level 0
-        "pool_bytes": B * (n * n * 4.0 + (pyr - n * n * 4.0)),                                          # read level 0, write levels 1-3
+        "volume_bytes": B * (n * 256 * 4.0 + lvl[0] + (lvl[1] if fused else 0.0)) + (1 if shared_key else B) * n * 256 * 4.0,   # GEMM: read fmaps, write level 0 (+ level 1)
+        "pool_bytes": B * ((lvl[1] + lvl[2] + lvl[3]) if fused else pyr),                                # read level 1 (or 0), write the levels below
+        "pool_reread_bytes": B * (lvl[1] if fused else lvl[0]),                                         # the level the pooling kernel reads back
         "lookup_bytes": B * n * (400 * 4.0 + 324 * 4.0 + 8.0),                                          # per launch
         "upsample_bytes": B * (n * 576 * 4.0 + n * 8.0 + H * W * 8.0),
         "warp_bytes": B * (H * W * 8.0 + H * W * 3.0) + H * W * 3.0,

@@ -73,9 +73,12 @@ struct ConvK {
     unsigned magic_cin, magic_kw;   // ceil(2^32/d) for d = cin, KW (0 when d == 1): k/d = umulhi(k, magic)
     unsigned kw1_mask;              // all ones when KW == 1 (then tap / KW = tap), else 0
     int bytes0, bytes1, bytesw;     // extents of the two input segments and of the weight matrix (per z)
+    // kEpiVolPool (correlation volume): level 1 of the pyramid written from the accumulators (see the epilogue)
+    float* pool_out; long pool_zs; int pool_wb0, pool_wb1, pool_slice1;
 };
 
 constexpr int kEpiPlainT = 4;   // internal: OFX_EPI_PLAIN with a sigmoid / tanh activation (own instantiation, own register budget)
+constexpr int kEpiVolPool = 5;  // internal: plain store of the blocked correlation volume + its 2x2 average (pyramid level 1)
 constexpr int kKAlign = 32;   // packed weights are zero-padded along K to this (a multiple of every BK)
 
 // KS = 2 ("paired pipelines", small grids only): the workgroup has a second set of four waves that runs the
@@ -525,7 +528,8 @@ __global__ __launch_bounds__(256 * KS, (BK == 16 && KS == 1) ? 3 : 1) void igemm
     const float act_lo = p.act == OFX_ACT_RELU ? 0.0f : -3.402823466e38f;
     const float res_lo = has_res ? 0.0f : -3.402823466e38f;
     constexpr bool TRANSC = EPI == kEpiPlainT;            // plain epilogue with sigmoid / tanh
-    constexpr int EPK = TRANSC ? OFX_EPI_PLAIN : EPI;     // epilogue kind
+    constexpr bool VOLPOOL = EPI == kEpiVolPool;          // blocked correlation volume: also writes pyramid level 1
+    constexpr int EPK = (TRANSC || VOLPOOL) ? OFX_EPI_PLAIN : EPI;     // epilogue kind
     auto epilogue = [&](auto full_tag) {
         constexpr bool FULL = decltype(full_tag)::value;  // tile entirely inside M: no per-row masks
 #pragma unroll
@@ -575,6 +579,23 @@ __global__ __launch_bounds__(256 * KS, (BK == 16 && KS == 1) ? 3 : 1) void igemm
                 const __amdgpu_buffer_rsrc_t rs_w = rsrc_of(pw, ldw);
                 const int vo_w = ((mb0 * ldw + cw) * 4) | cmask;
                 const bool need1 = EPK == OFX_EPI_PLAIN ? has_res : EPK == OFX_EPI_GRU_ZR ? r_half : true;
+                // VOLPOOL: the 32 columns of this sub-tile are one 4x8 block of the pixel's level-0 slice (column order is
+                // blocked, n0 % 32 == 0); its 2x2 averages are a 2x4 patch of level 1.  The partners of column c are c ^ 1
+                // (same row, next column) and c ^ 8 (next row): two DPP adds inside the 16-lane row, then the lanes with
+                // bits 0 and 3 clear hold the sums.
+                __amdgpu_buffer_rsrc_t rs_p = rs_w;
+                int vo_p = 0;
+                bool pool_lane = false;
+                if constexpr (VOLPOOL) {
+                    const int blk = __builtin_amdgcn_readfirstlane(nbase) >> 5;
+                    const int by = blk / p.pool_wb0, bx = blk - by * p.pool_wb0;
+                    const int c = lane & 31;
+                    const int y1 = (by << 1) + ((c >> 4) & 1), x1 = (bx << 2) + ((c >> 1) & 3);
+                    const int idx1 = ((((y1 >> 2) * p.pool_wb1) + (x1 >> 3)) << 5) + ((y1 & 3) << 3) + (x1 & 7);
+                    pool_lane = nok && (c & 9) == 0;
+                    rs_p = __builtin_amdgcn_make_buffer_rsrc((void*)(p.pool_out + (long)z * p.pool_zs), (short)0, (int)((long)Mrows * p.pool_slice1 * 4), 0x00020000);
+                    vo_p = ((mb0 * p.pool_slice1 + idx1) * 4) | (pool_lane ? 0 : kOOB);
+                }
 #pragma unroll
                 for (int ib = 0; ib < TM * (16 / EB); ++ib) {
                     // EB elements per phase: enough loads in flight to cover the latency, few enough live
@@ -622,6 +643,11 @@ __global__ __launch_bounds__(256 * KS, (BK == 16 && KS == 1) ? 3 : 1) void igemm
                             v[q] = (1.0f - x1[q]) * x2[q] + x1[q] * ofx_tanh(v[q]);
                         }
                         stf(v[q], rs_w, vo_w | mask_of(row_of(q)), row_of(q) * ldw * 4);
+                        if constexpr (VOLPOOL) {
+                            const float s1 = v[q] + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v[q]), 0xB1, 0xF, 0xF, false));   // quad_perm [1,0,3,2]: lane ^ 1
+                            const float s2 = s1 + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(s1), 0x128, 0xF, 0xF, false));    // row_ror:8: lane ^ 8
+                            stf(s2 * 0.25f, rs_p, vo_p | mask_of(row_of(q)), row_of(q) * p.pool_slice1 * 4);
+                        }
                     }
                 }
             }
@@ -649,6 +675,12 @@ int launch_tile(const ConvK& k, int epi, bool norm, int nz, hipStream_t s) {
         case OFX_EPI_GRU_ZR: hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, OFX_EPI_GRU_ZR, false, BK, PREC, KS, SK>), grid, block, 0, s, k); break;
         case OFX_EPI_GRU_Q: hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, OFX_EPI_GRU_Q, false, BK, PREC, KS, SK>), grid, block, 0, s, k); break;
         case OFX_EPI_FLOW: hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, OFX_EPI_FLOW, false, BK, PREC, KS, SK>), grid, block, 0, s, k); break;
+        case kEpiVolPool:
+            if constexpr (BM == 128 && BN == 128 && BK == 16 && PREC == 0 && KS == 1 && !SK) {
+                hipLaunchKernelGGL((igemm_kernel<128, 128, 64, 64, kEpiVolPool, false, 16, 0, 1, false>), grid, block, 0, s, k);
+                break;
+            }
+            return OFX_EINVAL;
         default: return OFX_EINVAL;
     }
     return ofx_launch_status();
@@ -656,7 +688,31 @@ int launch_tile(const ConvK& k, int epi, bool norm, int nz, hipStream_t s) {
 
 }  // namespace
 
+namespace {
+struct VolPool {            // set by ofx_conv2d_volpool around one ofx_conv2d_alpha call (same thread)
+    bool on = false;
+    float* out = nullptr;
+    long zs = 0;
+    int wb0 = 0, wb1 = 0, slice1 = 0;
+};
+thread_local VolPool tl_pool;
+}  // namespace
+
 extern "C" int ofx_conv2d(const ofx_conv_desc* d, void* stream) { return ofx_conv2d_alpha(d, 1.0f, stream); }
+
+// Correlation volume in the blocked layout + pyramid level 1 from the accumulators (corr.hip decides when it applies:
+// fp32, 128x128 tiles, h % 8 == 0 and w % 16 == 0 so that level 1 is tiled by whole blocks).  pool_out: level 1,
+// [nz][M][slice1]; wb0 / wb1: blocks per slice row of level 0 / 1.
+int ofx_conv2d_volpool(const ofx_conv_desc* d, float alpha, float* pool_out, long pool_zs, int wb0, int wb1, int slice1, void* stream) {
+    OFX_REQUIRE(d && pool_out && wb0 > 0 && wb1 > 0 && slice1 > 0, OFX_EINVAL);
+    OFX_REQUIRE(d->precision == OFX_PREC_FP32 && d->epi == OFX_EPI_PLAIN && d->act == OFX_ACT_NONE && !d->res && !d->addend && !d->nmean &&
+                    !d->scale && !d->shift && d->Cout % 128 == 0 && d->tile == 0,
+                OFX_EINVAL);
+    tl_pool.on = true; tl_pool.out = pool_out; tl_pool.zs = pool_zs; tl_pool.wb0 = wb0; tl_pool.wb1 = wb1; tl_pool.slice1 = slice1;
+    const int st = ofx_conv2d_alpha(d, alpha, stream);
+    tl_pool = VolPool{};
+    return st;
+}
 
 extern "C" int ofx_conv2d_alpha(const ofx_conv_desc* d, float alpha, void* stream) {
     OFX_REQUIRE(d != nullptr, OFX_EINVAL);
@@ -701,7 +757,10 @@ extern "C" int ofx_conv2d_alpha(const ofx_conv_desc* d, float alpha, void* strea
                 part.out = d->out + r0 * d->ldo;
                 if (d->res) part.res = d->res + r0 * d->ldres;
                 if (d->addend) part.addend = d->addend + r0 * d->ldadd;
+                const VolPool saved = tl_pool;
+                if (saved.on) tl_pool.out = saved.out + r0 * saved.slice1;
                 const int st = ofx_conv2d_alpha(&part, alpha, stream);
+                tl_pool = saved;
                 if (st) return st;
             }
             return 0;
@@ -737,6 +796,9 @@ extern "C" int ofx_conv2d_alpha(const ofx_conv_desc* d, float alpha, void* strea
     OFX_REQUIRE(k.Kpad < 65536, OFX_EINVAL);                       // umulhi division is exact in this range
     if (d->in1) OFX_REQUIRE(d->c0 % kKAlign == 0, OFX_EALIGN);           // a K chunk never straddles the two segments
     k.bytes0 = (int)ext0; k.bytes1 = (int)ext1; k.bytesw = (int)extw;
+    k.pool_out = tl_pool.on ? tl_pool.out : nullptr; k.pool_zs = tl_pool.zs; k.pool_wb0 = tl_pool.wb0; k.pool_wb1 = tl_pool.wb1;
+    k.pool_slice1 = tl_pool.slice1;
+    if (tl_pool.on) OFX_REQUIRE(M * (long)tl_pool.slice1 * 4 < (1L << 31) - 64, OFX_EINVAL);
 
     switch (d->epi) {
         case OFX_EPI_PLAIN:
@@ -833,6 +895,13 @@ extern "C" int ofx_conv2d_alpha(const ofx_conv_desc* d, float alpha, void* strea
         if (bm == 128 && bn == 64) return wsplit ? launch_tile<128, 64, 64, 32, 16, 2>(k, d->epi, norm, nz, s) : launch_tile<128, 64, 64, 32, 16, 1>(k, d->epi, norm, nz, s);
         if (bm == 64 && bn == 64) return wsplit ? launch_tile<64, 64, 32, 32, 16, 2>(k, d->epi, norm, nz, s) : launch_tile<64, 64, 32, 32, 16, 1>(k, d->epi, norm, nz, s);
         return OFX_EINVAL;
+    }
+    if (tl_pool.on) {
+        k.mtiles = (int)((M + 127) / 128);
+        k.ntiles = (d->Cout + 127) / 128;
+        k.group_m = k.ntiles >= 8 ? 8 : 1;
+        k.ksplit = 1;
+        return launch_tile<128, 128, 64, 64, 16>(k, kEpiVolPool, false, nz, s);
     }
     if (bm == 256 && bn == 64) return launch_tile<256, 64, 64, 64, 16>(k, d->epi, norm, nz, s);
     if (bm == 128 && bn == 192) return launch_tile<128, 192, 64, 96, 16>(k, d->epi, norm, nz, s);

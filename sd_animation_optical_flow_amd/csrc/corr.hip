@@ -36,6 +36,7 @@ struct PoolArgs {
     int h[4], w[4], wb[4];
     int slice[4];             // floats per pixel slice per level
     int levels;               // total pyramid levels (2..4)
+    int from_l1;              // level 1 already exists (written by the volume GEMM's epilogue): start there
 };
 
 // LDS map (row-major, h x w) -> one blocked slice in HBM, padding elements written as zeros, 16-byte stores
@@ -62,11 +63,28 @@ __global__ __launch_bounds__(256) void pyramid_pool_kernel(const PoolArgs a) {
     float* s2 = s1 + a.h[1] * a.w[1];         // level 2
     float* s3 = s2 + a.h[2] * a.w[2];         // level 3
     const long p = blockIdx.x;                // source pixel (row of the volume)
+    const int h1 = a.h[1], w1 = a.w[1], wb0 = a.wb[0];
+    if (a.from_l1) {
+        // level 1 came out of the GEMM (blocked): bring it into the row-major LDS map and go on from there
+        const float* l1 = a.lv[1] + p * (long)a.slice[1];
+        for (int e = threadIdx.x * 4; e < a.slice[1]; e += 256 * 4) {
+            const float4 v = *reinterpret_cast<const float4*>(l1 + e);
+            const int blk = e >> 5, off = e & 31;
+            const int by = blk / a.wb[1], bx = blk - by * a.wb[1];
+            const int y = (by << 2) + (off >> 3), x = (bx << 3) + (off & 7);
+            if (y < h1) {
+                float* r = s1 + y * w1 + x;
+                if (x < w1) r[0] = v.x;
+                if (x + 1 < w1) r[1] = v.y;
+                if (x + 2 < w1) r[2] = v.z;
+                if (x + 3 < w1) r[3] = v.w;
+            }
+        }
+    }
     const float* src = a.l0 + p * (long)a.slice[0];
     // level 1 from ONE read of level 0: a 4x8 block pools into a 2x4 patch, so an item is (block, row pair, column half):
     // two 16-byte loads -> two outputs; four items per trip keep 8 x 16 B in flight per lane
-    const int nitem = (a.slice[0] >> 5) << 2;
-    const int h1 = a.h[1], w1 = a.w[1], wb0 = a.wb[0];
+    const int nitem = a.from_l1 ? 0 : (a.slice[0] >> 5) << 2;
     for (int i0 = 0; i0 < nitem; i0 += 4 * 256) {
         float4 t[4], u[4];
 #pragma unroll
@@ -89,7 +107,7 @@ __global__ __launch_bounds__(256) void pyramid_pool_kernel(const PoolArgs a) {
         }
     }
     __syncthreads();
-    store_blocked(s1, a.lv[1] + p * (long)a.slice[1], h1, w1, a.wb[1], a.slice[1]);
+    if (!a.from_l1) store_blocked(s1, a.lv[1] + p * (long)a.slice[1], h1, w1, a.wb[1], a.slice[1]);
     if (a.levels < 3) return;
     const int h2 = a.h[2], w2 = a.w[2];
     for (int i = threadIdx.x; i < h2 * w2; i += 256) {
@@ -516,8 +534,14 @@ int ofx_local_corr_launch(const float* f1, const float* f2, const float* coords,
 
 int ofx_corr_slice_floats_l(int hl, int wl) { return ((hl + 3) >> 2) * ((wl + 7) >> 3) * 32; }
 
-int ofx_corr_pool_launch(const float* l0, float* l1, float* l2, float* l3, int B, int h, int w, int levels, hipStream_t s) {
+// The volume GEMM can write level 1 itself when level 1 is tiled by whole 4x8 blocks and every level-0 block maps to a
+// whole 2x4 patch of it
+bool ofx_corr_volpool_ok(int h, int w) { return h % 8 == 0 && w % 16 == 0; }
+
+int ofx_corr_pool_launch(const float* l0, float* l1, float* l2, float* l3, int B, int h, int w, int levels, hipStream_t s, bool from_l1) {
     PoolArgs a{};
+    a.from_l1 = from_l1 ? 1 : 0;
+    if (from_l1 && levels < 3) return 0;
     a.l0 = l0; a.lv[1] = l1; a.lv[2] = l2; a.lv[3] = l3;
     for (int l = 0; l < 4; ++l) {
         a.h[l] = h >> l; a.w[l] = w >> l;
@@ -558,6 +582,7 @@ int ofx_corr_volume(const float* f1, const float* f2, float* const* pyr, int B, 
     const long N = (long)h * w;
     const long Nb = ofx_corr_slice_floats_l(h, w);
     hipStream_t s = (hipStream_t)stream;
+    const bool fused = levels >= 2 && ofx_corr_volpool_ok(h, w) && Nb % 128 == 0 && N * (long)ofx_corr_slice_floats_l(h >> 1, w >> 1) * 4 < (1L << 31) - 64;
     // the GEMM's B operand in blocked row order (stream-ordered scratch: freed behind the GEMM on the same stream)
     float* f2b = nullptr;
     OFX_HIP_CHECK(hipMallocAsync((void**)&f2b, (size_t)B * Nb * D * sizeof(float), s));
@@ -572,13 +597,17 @@ int ofx_corr_volume(const float* f1, const float* f2, float* const* pyr, int B, 
         d.B = 1; d.Hin = h; d.Win = w; d.Hout = h; d.Wout = w; d.Cout = (int)Nb;
         d.KH = 1; d.KW = 1; d.stride = 1; d.padH = 0; d.padW = 0;
         d.act = OFX_ACT_NONE; d.epi = OFX_EPI_PLAIN;
-        st = ofx_conv2d_alpha(&d, 1.0f / sqrtf((float)D), stream);   // D = 256 -> exactly /16
+        if (fused)   // level 1 from the accumulators: level 0 is not read again
+            st = ofx_conv2d_volpool(&d, 1.0f / sqrtf((float)D), pyr[1], N * ofx_corr_slice_floats_l(h >> 1, w >> 1), (w + 7) >> 3,
+                                    ((w >> 1) + 7) >> 3, ofx_corr_slice_floats_l(h >> 1, w >> 1), stream);
+        else
+            st = ofx_conv2d_alpha(&d, 1.0f / sqrtf((float)D), stream);   // D = 256 -> exactly /16
     }
     const hipError_t fe = hipFreeAsync(f2b, s);
     if (st) return st;
     if (fe != hipSuccess) return (int)fe;
     if (levels == 1) return 0;
-    return ofx_corr_pool_launch(pyr[0], pyr[1], levels > 2 ? pyr[2] : nullptr, levels > 3 ? pyr[3] : nullptr, B, h, w, levels, s);
+    return ofx_corr_pool_launch(pyr[0], pyr[1], levels > 2 ? pyr[2] : nullptr, levels > 3 ? pyr[3] : nullptr, B, h, w, levels, s, fused);
 }
 
 int ofx_corr_lookup(const float* const* pyr, const float* coords, float* out, int ldo, int B, int h, int w,

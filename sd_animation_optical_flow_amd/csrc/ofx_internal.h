@@ -39,6 +39,8 @@ static inline int ofx_launch_status() {
 
 // conv.hip: ofx_conv2d with an extra scalar multiplier on the accumulator (out = act(acc*alpha*scale + shift))
 extern "C" int ofx_conv2d_alpha(const ofx_conv_desc* d, float alpha, void* stream);
+// conv.hip: the blocked correlation volume GEMM that also writes pyramid level 1 from its accumulators
+int ofx_conv2d_volpool(const ofx_conv_desc* d, float alpha, float* pool_out, long pool_zs, int wb0, int wb1, int slice1, void* stream);
 
 // corr.hip / net_misc.hip: internal launchers used by the RAFT engine
 int ofx_local_corr_launch(const float* f1, const float* f2, const float* coords, float* out, long sb, long sn,
@@ -47,7 +49,9 @@ int ofx_local_corr_launch(const float* f1, const float* f2, const float* coords,
 // blocked pyramid layout (corr.hip): floats per pixel slice of an hl x wl level; fmap rows -> blocked order
 int ofx_corr_slice_floats_l(int hl, int wl);
 int ofx_corr_block_rows(const float* src, float* dst, int n, int h, int w, int D, hipStream_t s);
-int ofx_corr_pool_launch(const float* l0, float* l1, float* l2, float* l3, int B, int h, int w, int levels, hipStream_t s);
+int ofx_corr_pool_launch(const float* l0, float* l1, float* l2, float* l3, int B, int h, int w, int levels, hipStream_t s,
+                         bool from_l1 = false);
+bool ofx_corr_volpool_ok(int h, int w);
 // mask_bits.hip: binary threshold/edge source -> elliptical dilation on bit planes
 enum { OFX_MSRC_CONF_LT = 0, OFX_MSRC_CONF_NGT = 1, OFX_MSRC_EDGES = 3 };   // conf < t | !(conf > t) | Laplacian edges
 int ofx_mask_bits_launch(int src, const float* conf, float* log_conf, const uint8_t* image, const uint8_t* or_mask,
