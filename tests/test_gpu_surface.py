@@ -394,3 +394,33 @@ def test_clip_pipeline_end_to_end_over_a_workspace(algo, tmp_path):
     out2 = video.get_ai_frame(2)                                                      # default render: raw pixels where masked
     m = p.mask.cpu().numpy() == 255
     assert np.array_equal(out2[m], frames[2][m]) and np.array_equal(out2[~m], p.warped.cpu().numpy()[~m])
+
+
+def test_config_c5_1024x1024_flow_warp_mask_against_the_oracle(cuda, raft_sd):
+    """BASELINE config #5's frame size, the path's own half of it at full depth: one 1024x1024 pair, 20 iterations, flow
+    against the CPU oracle (EPE bar 1e-3 px), then warp + mask of a small batch against their oracles and the hand-off +
+    first-stage latent on top (finite, right shapes).  The generative half (UNet / sampler) is out of scope."""
+    from sd_animation_optical_flow_amd import handoff, ops
+    from sd_animation_optical_flow_amd.raft import RaftEngine
+    eng = RaftEngine(raft_sd)
+    H = W = 1024
+    g = torch.Generator().manual_seed(55)
+    base = torch.nn.functional.avg_pool2d(torch.rand((1, 3, H + 16, W + 16), generator=g), 7, 1, 3)
+    base = ((base - base.min()) / (base.max() - base.min()) * 255).round().to(torch.uint8)
+    key = base[0, :, 8:8 + H, 8:8 + W].permute(1, 2, 0).contiguous()
+    frames = torch.stack([base[0, :, 8 + dy:8 + dy + H, 8 + dx:8 + dx + W].permute(1, 2, 0) for dy, dx in ((3, -2), (-1, 4), (2, 2), (0, -3))]).contiguous()
+    flow = eng.forward(frames.cuda(), key.cuda(), iters=20)
+    _, up = RO.raft_forward(raft_sd, frames[:1].permute(0, 3, 1, 2).float(), key.permute(2, 0, 1)[None].float(), iters=20)
+    epe = (flow[0].cpu() - up[0].permute(1, 2, 0)).pow(2).sum(-1).sqrt().mean().item()
+    assert epe < 1e-3, epe
+    key_ai = (255 - key).contiguous().cuda()
+    conf = torch.rand((4, H, W), generator=g).cuda()
+    warped, mask = ops.warp_and_mask(key_ai, flow, conf, warp_mode="bilinear", thres=0.95, ksize=7)
+    ref_w = WO.warp_frame(key_ai.cpu().numpy(), flow[0].cpu().numpy(), mode="bilinear")
+    d = np.abs(warped[0].cpu().numpy().astype(int) - ref_w.astype(int))
+    assert d.max() <= 1 and (d > 0).mean() < 1e-3
+    c0 = conf[0].cpu().numpy()
+    ref_m, _ = MO.generate_mask(c0, c0.copy(), 0.95, 7)
+    assert np.array_equal(mask[0].cpu().numpy(), ref_m)
+    t = handoff.prepare_inpaint_inputs(warped, frames.cuda(), mask, mask_blur=4)
+    assert tuple(t["image"].shape) == (4, 3, H, W) and bool(torch.isfinite(t["image"]).all())
