@@ -18,10 +18,11 @@
 
 namespace {
 
-constexpr int kSlices = 64;
+// slices of an image summed by separate workgroups: few images -> many slices, so that the statistics pass fills the chip
+static inline int gn_slices(int B) { return B >= 4 ? 64 : 256; }
 
 // per (image, slice) per-channel sums in f64 (same scheme as the instance-norm statistics of net_misc.hip)
-__global__ __launch_bounds__(256) void gn_partial_kernel(const float* __restrict__ x, double* __restrict__ part, long HW, int C) {
+__global__ __launch_bounds__(256) void gn_partial_kernel(const float* __restrict__ x, double* __restrict__ part, long HW, int C, int kSlices) {
     const int cg = C / 4;
     const int rows = 256 / cg > 0 ? 256 / cg : 1;
     const int b = blockIdx.y, sl = blockIdx.x;
@@ -65,37 +66,52 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const float* __restrict
     (void)rows;
 }
 
-// one workgroup per image: group statistics -> per-channel scale / shift (y = x * scale + shift)
+// one workgroup per image: group statistics -> per-channel scale / shift (y = x * scale + shift).  The 256 threads are
+// dealt to the groups (256 / groups threads each, every one summing its share of the slices in a fixed order, then one
+// thread per group adding the shares in index order: deterministic).
 __global__ __launch_bounds__(256) void gn_finalize_kernel(const double* __restrict__ part, const float* __restrict__ gamma,
                                                           const float* __restrict__ beta, float* __restrict__ scale,
-                                                          float* __restrict__ shift, long HW, int C, int groups, float eps) {
-    __shared__ double gs[256], gq[256];
+                                                          float* __restrict__ shift, long HW, int C, int groups, float eps, int kSlices) {
+    __shared__ double rs[256], rq[256];
+    __shared__ double gmu[256], grs[256];
     const int b = blockIdx.x;
     const int cpg = C / groups;
-    for (int g0 = 0; g0 < groups; g0 += 256) {
-        const int g = g0 + threadIdx.x;
-        if (g < groups) {
-            double s = 0, q = 0;
-            for (int sl = 0; sl < kSlices; ++sl)
-                for (int c = g * cpg; c < (g + 1) * cpg; ++c) {
-                    const double* o = part + (((long)b * kSlices + sl) * C + c) * 2;
-                    s += o[0];
-                    q += o[1];
+    const int tpg = groups >= 256 ? 1 : 256 / groups;          // threads per group
+    for (int g0 = 0; g0 < groups; g0 += 256 / tpg) {
+        const int gl = threadIdx.x / tpg, sub = threadIdx.x - gl * tpg;
+        const int g = g0 + gl;
+        double s = 0, q = 0;
+        if (g < groups)
+            for (int sl = sub; sl < kSlices; sl += tpg) {
+                const double* o = part + (((long)b * kSlices + sl) * C + g * cpg) * 2;
+                for (int c = 0; c < cpg; ++c) {
+                    s += o[2 * c];
+                    q += o[2 * c + 1];
                 }
+            }
+        rs[threadIdx.x] = s;
+        rq[threadIdx.x] = q;
+        __syncthreads();
+        if (sub == 0 && g < groups) {
+            s = 0; q = 0;
+            for (int k = 0; k < tpg; ++k) {
+                s += rs[threadIdx.x + k];
+                q += rq[threadIdx.x + k];
+            }
             const double n = (double)HW * cpg;
             const double mu = s / n;
             double var = q / n - mu * mu;
             if (var < 0) var = 0;
-            gs[threadIdx.x] = mu;
-            gq[threadIdx.x] = 1.0 / sqrt(var + (double)eps);
+            gmu[gl] = mu;
+            grs[gl] = 1.0 / sqrt(var + (double)eps);
         }
         __syncthreads();
         for (int c = threadIdx.x; c < C; c += 256) {
             const int g2 = c / cpg - g0;
-            if (g2 >= 0 && g2 < 256) {
-                const double rs = gq[g2] * (double)(gamma ? gamma[c] : 1.f);
-                scale[(long)b * C + c] = (float)rs;
-                shift[(long)b * C + c] = (float)((double)(beta ? beta[c] : 0.f) - gs[g2] * rs);
+            if (g2 >= 0 && g2 < 256 / tpg) {
+                const double r = grs[g2] * (double)(gamma ? gamma[c] : 1.f);
+                scale[(long)b * C + c] = (float)r;
+                shift[(long)b * C + c] = (float)((double)(beta ? beta[c] : 0.f) - gmu[g2] * r);
             }
         }
         __syncthreads();
@@ -195,7 +211,7 @@ inline long round_up(long v, long m) { return (v + m - 1) / m * m; }
 
 extern "C" {
 
-size_t ofx_groupnorm_scratch_bytes(int B, int C) { return (size_t)B * kSlices * C * 2 * sizeof(double) + (size_t)B * C * 2 * sizeof(float); }
+size_t ofx_groupnorm_scratch_bytes(int B, int C) { return (size_t)B * gn_slices(B) * C * 2 * sizeof(double) + (size_t)B * C * 2 * sizeof(float); }
 
 int ofx_groupnorm(const float* x, const float* gamma, const float* beta, float* out, void* scratch, size_t scratch_bytes, int B,
                   long HW, int C, int groups, float eps, int silu, void* stream) {
@@ -203,13 +219,14 @@ int ofx_groupnorm(const float* x, const float* gamma, const float* beta, float* 
     OFX_REQUIRE(C % 4 == 0 && ofx_aligned16(x) && ofx_aligned16(out) && ofx_aligned16(scratch), OFX_EALIGN);
     OFX_REQUIRE(scratch_bytes >= ofx_groupnorm_scratch_bytes(B, C), OFX_ENOMEM);
     hipStream_t s = (hipStream_t)stream;
+    const int kSlices = gn_slices(B);
     double* part = reinterpret_cast<double*>(scratch);
     float* scale = reinterpret_cast<float*>(part + (size_t)B * kSlices * C * 2);
     float* shift = scale + (size_t)B * C;
     {
         OfxProfScope prof("groupnorm_stats", s);
-        hipLaunchKernelGGL(gn_partial_kernel, dim3(kSlices, B), dim3(256), 0, s, x, part, HW, C);
-        hipLaunchKernelGGL(gn_finalize_kernel, dim3(B), dim3(256), 0, s, part, gamma, beta, scale, shift, HW, C, groups, eps);
+        hipLaunchKernelGGL(gn_partial_kernel, dim3(kSlices, B), dim3(256), 0, s, x, part, HW, C, kSlices);
+        hipLaunchKernelGGL(gn_finalize_kernel, dim3(B), dim3(256), 0, s, part, gamma, beta, scale, shift, HW, C, groups, eps, kSlices);
     }
     int st = ofx_launch_status();
     if (st) return st;
