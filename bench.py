@@ -272,6 +272,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true", help="skip the oracle check of one sampled pair")
     ap.add_argument("--no-single", action="store_true")
+    ap.add_argument("--no-handoff", action="store_true", help="skip the 1024x1024 SD-inpaint hand-off timing (config #5's non-generative half)")
     ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16x3"],
                     help="matrix-core arithmetic of the timed run (fp32 = the reference's; bf16x3 = opt-in split-bf16 fast mode)")
     ap.add_argument("--no-fast", action="store_true", help="skip the secondary bf16x3 measurement")
@@ -516,6 +517,31 @@ def main():
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t1) / reps
         out["single_pair"] = {"workload": "BASELINE configs[1]: one 512x768 pair", "ms": round(dt * 1e3, 3), "pairs_per_s": round(1 / dt, 2)}
+
+    if not args.no_handoff and world == 1:
+        # BASELINE configs[4]'s frame size, the half of it that is on the path: warp/mask outputs -> Pillow-exact inpaint inputs ->
+        # first-stage latent, one 1024x1024 frame per call, everything resident in HBM
+        from sd_animation_optical_flow_amd import handoff
+        from sd_animation_optical_flow_amd.vae import VaeEncoder, random_vae_state_dict
+        g5 = torch.Generator(device=dev).manual_seed(5)
+        fr5 = torch.randint(0, 256, (1, 1024, 1024, 3), dtype=torch.uint8, device=dev, generator=g5)
+        rf5 = torch.randint(0, 256, (1, 1024, 1024, 3), dtype=torch.uint8, device=dev, generator=g5)
+        mk5 = (torch.rand((1, 1024, 1024), device=dev, generator=g5) > 0.8).to(torch.uint8) * 255
+        vae = VaeEncoder(random_vae_state_dict(0), dev)
+
+        def hstep():
+            t5 = handoff.prepare_inpaint_inputs(fr5, rf5, mk5, mask_blur=4, device=dev)
+            return vae.get_first_stage_encoding(t5["image"])
+        for _ in range(2):
+            hstep()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(5):
+            z5 = hstep()
+        torch.cuda.synchronize()
+        out["sd_handoff_1024"] = {"workload": "BASELINE configs[4] frame size, non-generative half: inpaint inputs + first-stage latent, one 1024x1024 frame",
+                                  "ms": round((time.perf_counter() - t1) / 5 * 1e3, 3), "finite": bool(torch.isfinite(z5).all())}
+        del vae, fr5, rf5, mk5
 
     if not args.no_fast and world == 1 and args.precision == "fp32":
         # secondary measurement: the opt-in split-bf16 mode on the same clip, with its flow error against the fp32 run
