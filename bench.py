@@ -273,7 +273,7 @@ def main():
     ap.add_argument("--no-verify", action="store_true", help="skip the oracle check of one sampled pair")
     ap.add_argument("--no-single", action="store_true")
     ap.add_argument("--no-handoff", action="store_true", help="skip the 1024x1024 SD-inpaint hand-off timing (config #5's non-generative half)")
-    ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16x3"],
+    ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16x3", "bf16x6"],
                     help="matrix-core arithmetic of the timed run (fp32 = the reference's; bf16x3 = opt-in split-bf16 fast mode)")
     ap.add_argument("--no-fast", action="store_true", help="skip the secondary bf16x3 measurement")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
@@ -385,7 +385,7 @@ def main():
         "value": round(value, 3), "unit": "pairs/s", "n_gpus": n_gpus, "ranks_seen": ranks_seen, "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32" if args.precision == "fp32" else "bf16x3 (fp32 operands split into two bf16, fp32 accumulate)", "data": "synthetic",
+        "dtype": "f32" if args.precision == "fp32" else args.precision + " (fp32 operands split into bf16 pieces, fp32 accumulate)", "data": "synthetic",
         "config": {"workload": f"BASELINE configs[2]: {B}-frame 512x768 clip per GPU vs one shared key frame, RAFT {ITERS} iters "
                                f"fp32 + {args.warp_mode} warp + mask(conf<0.95, 7x7); configs[3] sharding at N>1",
                    "frames_per_gpu": B, "H": H, "W": W, "iters": ITERS, "parallelism": f"frame-parallel x{n_gpus}"},
@@ -546,25 +546,28 @@ def main():
     if not args.no_fast and world == 1 and args.precision == "fp32":
         # secondary measurement: the opt-in split-bf16 mode on the same clip, with its flow error against the fp32 run
         ref_flow = eng.forward(frames, key, iters=ITERS)
-        fast = RaftEngine(random_state_dict(0), dev, precision="bf16x3")
+        for mode, key_name, note in (("bf16x3", "fast_mode", "opt-in; not the headline value (the reference computes in fp32)"),
+                                     ("bf16x6", "split3_mode", "opt-in; three bf16 pieces per fp32 operand (exact), six products, fp32 accumulate: "
+                                      "fp32-level accuracy on the bf16 matrix cores; not the headline value")):
+            fast = RaftEngine(random_state_dict(0), dev, precision=mode)
 
-        def fstep():
-            fl = fast.forward(frames, key, iters=ITERS)
-            ops.warp_and_mask(key_ai, fl, conf, warp_mode=args.warp_mode, thres=0.95, ksize=7)
-            return fl
-        fl = fstep()
-        epe = float((fl - ref_flow).pow(2).sum(-1).sqrt().mean())
-        emax = float((fl - ref_flow).pow(2).sum(-1).sqrt().max())
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        for _ in range(args.steps):
-            fstep()
-        torch.cuda.synchronize()
-        dtf = (time.perf_counter() - t1) / args.steps
-        out["fast_mode"] = {"precision": "bf16x3", "value": round(B / dtf, 3), "unit": "pairs/s", "ms_per_step": round(dtf * 1e3, 3),
-                            "flow_epe_vs_fp32_px": epe, "flow_max_err_vs_fp32_px": emax,
-                            "note": "opt-in; not the headline value (the reference computes in fp32)"}
-        del fast, ref_flow
+            def fstep():
+                fl = fast.forward(frames, key, iters=ITERS)
+                ops.warp_and_mask(key_ai, fl, conf, warp_mode=args.warp_mode, thres=0.95, ksize=7)
+                return fl
+            fl = fstep()
+            epe = float((fl - ref_flow).pow(2).sum(-1).sqrt().mean())
+            emax = float((fl - ref_flow).pow(2).sum(-1).sqrt().max())
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                fstep()
+            torch.cuda.synchronize()
+            dtf = (time.perf_counter() - t1) / args.steps
+            out[key_name] = {"precision": mode, "value": round(B / dtf, 3), "unit": "pairs/s", "ms_per_step": round(dtf * 1e3, 3),
+                             "flow_epe_vs_fp32_px": epe, "flow_max_err_vs_fp32_px": emax, "note": note}
+            del fast
+        del ref_flow
 
     # child process with a hard time limit: neither the baseline nor the check may take the GPU number down with them
     import subprocess

@@ -187,6 +187,9 @@ int ofx_abs_diff_sum_u8(const uint8_t* a, long a_bstride, const uint8_t* b, long
 #define OFX_PREC_FP32   0
 #define OFX_PREC_BF16X3 1
 #define OFX_PREC_BF16X3_W 2   /* bf16x3 with `w` already in the split format of ofx_split_conv_weight */
+#define OFX_PREC_BF16X6 3     /* opt-in: fp32 operands split into THREE bf16 pieces (exact), the six products of weight >= 2^-16
+                                 on the bf16 matrix cores, fp32 accumulate: fp32-level accuracy (dropped terms < 2^-23), not the
+                                 bit pattern of an fmaf chain */
 
 typedef struct ofx_conv_desc {
     /* input: NHWC fp32, up to two channel segments (torch.cat along C without materialising) */
@@ -293,6 +296,7 @@ size_t ofx_raft_workspace_bytes(const ofx_raft* r, int B, int H, int W);
 #define OFX_RAFT_SHARED_IMG1  4   /* image1 is ONE image shared by the whole batch                 */
 #define OFX_RAFT_ALT_CORR     8   /* on-the-fly local correlation instead of the volume (alt_cuda_corr) */
 #define OFX_RAFT_BF16X3      16   /* opt-in: split-bf16 matrix-core arithmetic for every convolution / the volume */
+#define OFX_RAFT_BF16X6      64   /* opt-in: three-piece split-bf16 arithmetic (OFX_PREC_BF16X6) for every convolution / the volume */
 #define OFX_RAFT_SERIAL       32  /* keep every launch on the caller's stream (default: small batches run their
                                      independent chains on internal side streams, joined before returning) */
 

@@ -12,6 +12,10 @@
 //   PREC = 0  exact fp32: v_mfma_f32_32x32x2_f32 (f32 in, f32 accumulate, bit-identical to an fmaf
 //             chain, 157 TFLOP/s peak = the roofline of this kernel).  The reference runs fp32
 //             (mixed_precision=False, ofgen_keyframe_inpaint.py:57); this is the default everywhere.
+//   PREC = 3  opt-in "bf16x6": three bf16 pieces per operand (hi + mid + lo = the fp32 value exactly: 3 x 8 mantissa
+//             bits), the six products of weight >= 2^-16 (hh, hm, mh, mm, hl, lh) on v_mfma_f32_32x32x16_bf16 with fp32
+//             accumulation: what is dropped (ml, lm, ll) is below 2^-23 relative, i.e. fp32 rounding level, at 2.7x the
+//             fp32 MFMA rate.  Not bit-identical to an fmaf chain; see DESIGN.md "Precision".
 //   PREC = 1  opt-in "bf16x3": every operand is split at LDS-commit time into hi = bf16(x) and
 //             lo = bf16(x - hi); hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_bf16, f32 accumulate
 //             (~16 mantissa bits per product; measured flow EPE ~1e-4 px after 20 iterations).
@@ -87,7 +91,7 @@ constexpr int kKAlign = 32;   // packed weights are zero-padded along K to this 
 // latency of its two chunks in flight -- this doubles the loads in flight and the waves per SIMD without
 // touching the tile shape or the epilogue.
 template <int BM, int BN, int WM, int WN, int EPI, bool NORM, int BK, int PREC, int KS = 1, bool SK = false>
-__global__ __launch_bounds__(256 * KS, (BK == 16 && KS == 1) ? 3 : 1) void igemm_kernel(const ConvK p) {
+__global__ __launch_bounds__(256 * KS, (BK == 16 && KS == 1) ? (PREC == 3 ? 2 : 3) : 1) void igemm_kernel(const ConvK p) {
     constexpr int TM = WM / 32, TN = WN / 32;
     constexpr int WAVES_N = BN / WN;
     constexpr int LDK = BK + 4;               // LDS row stride in floats (144 B / 80 B): conflict-free b128 fragment reads
@@ -99,7 +103,8 @@ __global__ __launch_bounds__(256 * KS, (BK == 16 && KS == 1) ? 3 : 1) void igemm
     // PREC = 1 (bf16x3): every fp32 operand element is staged as two bf16 values hi = bf16(x), lo = bf16(x - hi)
     // (same 4 bytes per element); rows are BK bf16 + 16 B of padding (48 B / 80 B: conflict-free b128 reads)
     constexpr int ROWB = BK * 2 + 16;                       // bytes per staged bf16 row
-    constexpr int STAGE = PREC ? ((BM + BN_ST) * ROWB * 2) / 4 : (BM + BN_ST) * LDK;   // floats per stage
+    constexpr int NPC = PREC == 3 ? 3 : 2;                  // bf16 pieces per operand element
+    constexpr int STAGE = PREC ? ((BM + BN_ST) * ROWB * NPC) / 4 : (BM + BN_ST) * LDK;   // floats per stage
     static_assert((BM / WM) * (BN / WN) == 4, "4 waves per workgroup");
     static_assert(KS == 1 || KS == 2, "one or two pipelines");
     static_assert(KS == 1 || 2 * STAGE * KS >= 256 * TM * TN * 16, "accumulator exchange must fit the staging buffers");
@@ -304,8 +309,38 @@ __global__ __launch_bounds__(256 * KS, (BK == 16 && KS == 1) ? 3 : 1) void igemm
         *reinterpret_cast<b4*>(lo_row) = l;
     };
 
+    // fp32 -> (hi, mid, lo) bf16 triple: x = hi + mid + lo exactly unless lo underflows (3 x 8 mantissa bits)
+    auto split_store3 = [&](char* hi_row, char* mid_row, char* lo_row, float4 v) __attribute__((always_inline)) {
+        typedef float f4 __attribute__((ext_vector_type(4)));
+        typedef __bf16 b4 __attribute__((ext_vector_type(4)));
+        const f4 x = {v.x, v.y, v.z, v.w};
+        const b4 h = __builtin_convertvector(x, b4);
+        const f4 r1 = x - __builtin_convertvector(h, f4);
+        const b4 m = __builtin_convertvector(r1, b4);
+        const f4 r2 = r1 - __builtin_convertvector(m, f4);
+        const b4 l = __builtin_convertvector(r2, b4);
+        *reinterpret_cast<b4*>(hi_row) = h;
+        *reinterpret_cast<b4*>(mid_row) = m;
+        *reinterpret_cast<b4*>(lo_row) = l;
+    };
+
     auto commit = [&](float* stage) __attribute__((always_inline)) {
-        if constexpr (PREC == 0) {
+        if constexpr (PREC == 3) {
+            char* a0 = reinterpret_cast<char*>(stage);
+            char* b0 = a0 + 3 * BM * ROWB;
+#pragma unroll
+            for (int i = 0; i < A_PER; ++i) {
+                const int o = (r0 + RPG * i) * ROWB + kq * 8;
+                split_store3(a0 + o, a0 + BM * ROWB + o, a0 + 2 * BM * ROWB + o, norm_a(i));
+            }
+#define OFX_B_COMMIT(i) \
+    if constexpr (B_PER > i) { \
+        const int o = (r0 + RPG * i) * ROWB + kq * 8; \
+        split_store3(b0 + o, b0 + BN_ST * ROWB + o, b0 + 2 * BN_ST * ROWB + o, rb##i); \
+    }
+            OFX_B_COMMIT(0) OFX_B_COMMIT(1) OFX_B_COMMIT(2) OFX_B_COMMIT(3)
+#undef OFX_B_COMMIT
+        } else if constexpr (PREC == 0) {
             float* As = stage;
             float* Bs = As + BM * LDK;
 #pragma unroll
@@ -372,6 +407,41 @@ __global__ __launch_bounds__(256 * KS, (BK == 16 && KS == 1) ? 3 : 1) void igemm
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].y, fb[j].y, acc[i][j], 0, 0, 0);
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].z, fb[j].z, acc[i][j], 0, 0, 0);
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].w, fb[j].w, acc[i][j], 0, 0, 0);
+                    }
+            }
+        } else if constexpr (PREC == 3) {
+            // bf16x6: the six products of weight >= 2^-16, smallest first, fp32 accumulate
+            typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+            const char* a0 = reinterpret_cast<const char*>(smem + (kt & 1) * STAGE);
+            const char* b0 = a0 + 3 * BM * ROWB;
+#pragma unroll
+            for (int ks = 0; ks < BK / 16; ++ks) {
+                bf16x8 ah[TM], am[TM], al[TM], bh[TN], bm_[TN], bl[TN];
+                const int ko = ks * 32 + (lane >> 5) * 16;
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    const int o = (wm * WM + i * 32 + frag_row) * ROWB + ko;
+                    ah[i] = *reinterpret_cast<const bf16x8*>(a0 + o);
+                    am[i] = *reinterpret_cast<const bf16x8*>(a0 + BM * ROWB + o);
+                    al[i] = *reinterpret_cast<const bf16x8*>(a0 + 2 * BM * ROWB + o);
+                }
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const int o = (wn * WN + j * 32 + frag_row) * ROWB + ko;
+                    bh[j] = *reinterpret_cast<const bf16x8*>(b0 + o);
+                    bm_[j] = *reinterpret_cast<const bf16x8*>(b0 + BN_ST * ROWB + o);
+                    bl[j] = *reinterpret_cast<const bf16x8*>(b0 + 2 * BN_ST * ROWB + o);
+                }
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[i], bm_[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[i], bh[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bm_[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
                     }
             }
         } else {
@@ -889,6 +959,12 @@ extern "C" int ofx_conv2d_alpha(const ofx_conv_desc* d, float alpha, void* strea
         else if (bn != 64) bn = 128;
         k.ntiles = (d->Cout + bn - 1) / bn;
         k.group_m = k.ntiles >= 8 ? 8 : 1;
+        if (d->precision == OFX_PREC_BF16X6) {
+            if (bm == 128 && bn == 128) return launch_tile<128, 128, 64, 64, 16, 3>(k, d->epi, norm, nz, s);
+            if (bm == 128 && bn == 64) return launch_tile<128, 64, 64, 32, 16, 3>(k, d->epi, norm, nz, s);
+            if (bm == 64 && bn == 64) return launch_tile<64, 64, 32, 32, 16, 3>(k, d->epi, norm, nz, s);
+            return OFX_EINVAL;
+        }
         const bool wsplit = d->precision == OFX_PREC_BF16X3_W;
         if (bm == 128 && bn == 128 && tile_bk == 32 && !wsplit) return launch_tile<128, 128, 64, 64, 32, 1>(k, d->epi, norm, nz, s);
         if (bm == 128 && bn == 128) return wsplit ? launch_tile<128, 128, 64, 64, 16, 2>(k, d->epi, norm, nz, s) : launch_tile<128, 128, 64, 64, 16, 1>(k, d->epi, norm, nz, s);

@@ -662,7 +662,7 @@ int ofx_raft_forward(ofx_raft* r, const uint8_t* image1, const uint8_t* image2, 
     const long N = (long)h * w;
     const long M = (long)B * N;
     const int bgr = (flags & OFX_RAFT_BGR) ? 1 : 0;
-    const int prec = (flags & OFX_RAFT_BF16X3) ? OFX_PREC_BF16X3 : OFX_PREC_FP32;
+    const int prec = (flags & OFX_RAFT_BF16X6) ? OFX_PREC_BF16X6 : (flags & OFX_RAFT_BF16X3) ? OFX_PREC_BF16X3 : OFX_PREC_FP32;
     const bool sh1 = flags & OFX_RAFT_SHARED_IMG1, sh2 = flags & OFX_RAFT_SHARED_IMG2;
     const bool alt = flags & OFX_RAFT_ALT_CORR;
     const long img_bytes = (long)H * W * 3;
@@ -778,7 +778,7 @@ int ofx_raft_forward_pairs(ofx_raft* r, const uint8_t* images, int n_images, con
     const int h = H / 8, w = W / 8;
     const long N = (long)h * w;
     const int bgr = (flags & OFX_RAFT_BGR) ? 1 : 0;
-    const int prec = (flags & OFX_RAFT_BF16X3) ? OFX_PREC_BF16X3 : OFX_PREC_FP32;
+    const int prec = (flags & OFX_RAFT_BF16X6) ? OFX_PREC_BF16X6 : (flags & OFX_RAFT_BF16X3) ? OFX_PREC_BF16X3 : OFX_PREC_FP32;
     const long img_bytes = (long)H * W * 3;
     int st = 0;
     // every image is encoded ONCE (feature + context), however many pairs it takes part in: a 15-frame

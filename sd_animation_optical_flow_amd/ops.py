@@ -276,7 +276,7 @@ def conv2d_nhwc(x: torch.Tensor, w_packed: torch.Tensor, kh: int, kw: int, cout:
     d.B, d.Hin, d.Win, d.Hout, d.Wout, d.Cout = B, H, W, Ho, Wo, cout
     d.KH, d.KW, d.stride, d.padH, d.padW = kh, kw, stride, ph, pw
     d.act, d.epi, d.tile = ACTS[act], EPI_PLAIN, tile
-    d.precision = {"fp32": 0, "bf16x3": 1, "bf16x3_w": 2}[precision]   # bf16x3_w: weight from split_conv_weight
+    d.precision = {"fp32": 0, "bf16x3": 1, "bf16x3_w": 2, "bf16x6": 3}[precision]   # bf16x3_w: weight from split_conv_weight
     if splitk_ws is not None:       # uint8 scratch whose first 64 KiB are zero (see ofx_conv_desc.splitk_ws): allows split-K
         ws = _chk(splitk_ws, "splitk_ws", torch.uint8)
         d.splitk_ws, d.splitk_ws_bytes = ws.data_ptr(), ws.numel()

@@ -16,15 +16,16 @@ import torch.nn.functional as F
 from . import _lib
 from ._lib import check
 
-FLAG_BGR, FLAG_SHARED_IMG2, FLAG_SHARED_IMG1, FLAG_ALT_CORR, FLAG_BF16X3, FLAG_SERIAL = 1, 2, 4, 8, 16, 32
-PRECISIONS = {"fp32": 0, "bf16x3": FLAG_BF16X3}
+FLAG_BGR, FLAG_SHARED_IMG2, FLAG_SHARED_IMG1, FLAG_ALT_CORR, FLAG_BF16X3, FLAG_SERIAL, FLAG_BF16X6 = 1, 2, 4, 8, 16, 32, 64
+PRECISIONS = {"fp32": 0, "bf16x3": FLAG_BF16X3, "bf16x6": FLAG_BF16X6}
 
 
 class RaftEngine:
     def __init__(self, state_dict: Dict[str, torch.Tensor], device: Optional[torch.device] = None, precision: str = "fp32"):
-        """precision: 'fp32' (default; exact fp32 matrix-core arithmetic, the reference's) or 'bf16x3' (opt-in fast
+        """precision: 'fp32' (default; exact fp32 matrix-core arithmetic, the reference's), 'bf16x3' (opt-in fast
         mode: operands split into two bf16 values, three bf16 MFMAs per product, fp32 accumulate; flow EPE
-        ~1e-4 px against the fp32 path)."""
+        ~1e-4 px against the fp32 path) or 'bf16x6' (opt-in: three bf16 pieces = the fp32 value exactly, six
+        products, fp32 accumulate: fp32-level accuracy on the bf16 matrix cores)."""
         if precision not in PRECISIONS:
             raise ValueError(f"precision must be one of {sorted(PRECISIONS)}")
         self.precision = precision

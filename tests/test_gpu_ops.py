@@ -136,6 +136,31 @@ def test_conv2d_bf16x3_mode(cuda, case):
     assert torch.equal(outw, out16)
 
 
+@pytest.mark.parametrize("case", [(2, 24, 20, 64, 64, 3, 3, 1), (1, 33, 17, 256, 256, 1, 5, 1), (1, 16, 16, 324, 256, 1, 1, 1),
+                                  (1, 40, 24, 96, 192, 3, 3, 2), (1, 64, 48, 3, 64, 7, 7, 2)])
+def test_conv2d_bf16x6_mode_is_fp32_accurate(cuda, case):
+    """Opt-in three-piece split: hi + mid + lo is the fp32 operand exactly and only products below 2^-23 are dropped,
+    so the error against a float64 convolution must be of the SAME size as the native fp32 path's."""
+    ops = _ops()
+    B, H, W, ci, co, kh, kw, stride = case
+    g = torch.Generator().manual_seed(sum(case) + 1)
+    x = torch.randn((B, ci, H, W), generator=g)
+    w = torch.randn((co, ci, kh, kw), generator=g) / np.sqrt(ci * kh * kw)
+    b = torch.randn((co,), generator=g)
+    ref = F.conv2d(x.double(), w.double(), b.double(), stride=stride, padding=(kh // 2, kw // 2)).float()
+    wp = ops.pack_conv_weight(w).cuda()
+    xin = nhwc(x)
+    if ci == 3:
+        xin = torch.cat([xin, torch.zeros_like(xin[..., :1])], -1).contiguous()
+        wp = ops.pack_conv_weight(torch.cat([w, torch.zeros_like(w[:, :1])], 1)).cuda()
+    out32 = ops.conv2d_nhwc(xin, wp, kh, kw, co, stride=stride, shift=b.cuda())
+    out6 = ops.conv2d_nhwc(xin, wp, kh, kw, co, stride=stride, shift=b.cuda(), precision="bf16x6")
+    e32 = (nchw(out32) - ref).abs().max().item()
+    e6 = (nchw(out6) - ref).abs().max().item()
+    assert e32 < 2e-5 and e6 < 2e-5 and e6 < 3 * e32 + 1e-6, (e32, e6)
+    assert not torch.equal(out6, out32)                      # a different summation, not the fp32 kernel by accident
+
+
 def test_conv2d_two_segments_residual_and_scale(cuda):
     ops = _ops()
     g = torch.Generator().manual_seed(3)

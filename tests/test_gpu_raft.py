@@ -149,6 +149,20 @@ def test_bf16x3_fast_mode_stays_inside_the_epe_bar(cuda, raft_sd):
         assert epe > 1e-6            # not the fp32 path by accident
 
 
+def test_bf16x6_mode_matches_fp32_to_rounding_level(cuda, raft_sd, engine):
+    """Three-piece split-bf16 arithmetic: the flow must sit as close to the oracle as the native fp32 path does."""
+    from sd_animation_optical_flow_amd.raft import RaftEngine
+    six = RaftEngine(raft_sd, precision="bf16x6")
+    for (H, W, B, seed) in ((128, 160, 2, 11), (256, 384, 1, 12)):
+        key, frames = _frames(seed, B, H, W)
+        _, up_ref = _oracle_flow(raft_sd, frames, key[None].repeat(B, 1, 1, 1), 20)
+        up6 = six.forward(frames.cuda(), key.cuda(), iters=20)
+        up32 = engine.forward(frames.cuda(), key.cuda(), iters=20)
+        e6, e32 = _epe(up6.cpu(), up_ref), _epe(up32.cpu(), up_ref)
+        assert e6 < 1e-3 and e6 < 4 * e32 + 2e-5, (e6, e32)
+        assert not torch.equal(up6, up32)
+
+
 def test_non_multiple_of_8_is_padded_like_input_padder(engine, raft_sd):
     H, W = 100, 90
     key, frames = _frames(5, 1, H, W)
