@@ -149,8 +149,11 @@ int ofx_softmax_rows(float* x, long rows, long ld, int n, float scale, const flo
 /* out[z] = softmax(q[z] k[z]^T * scale + bias) v[z] for z < BH; q [BH,Nq,D], k/v [BH,Nk,D], out [BH,Nq,D], fp32, D % 4 == 0.
  * The semantics of xformers.ops.memory_efficient_attention(q, k, v, attn_bias) (ldm/modules/attention.py:314,426) and of
  * AttnBlock.forward (model.py:179-203, BH = batch, D = channels).  bias: NULL, [Nq,Nk] shared by every z
- * (bias_bstride = 0) or [BH,Nq,Nk] (bias_bstride = Nq*Nk).  Unfused: both GEMMs on the fp32 matrix cores, the score matrix
- * in the workspace (ofx_attention_workspace_bytes, 16-byte aligned; slice BH to bound it). */
+ * (bias_bstride = 0) or [BH,Nq,Nk] (bias_bstride = Nq*Nk); -inf entries mask keys (a row with every key masked is NaN,
+ * like softmax).  D in {40, 64, 80, 128, 160} (the UNet's head sizes) runs one fused kernel: online softmax, the scores
+ * never leave the CU, ofx_attention_workspace_bytes() = 0 and `workspace` may be NULL.  Other D (the VAE's single
+ * 512-wide head) run unfused: both GEMMs on the fp32 matrix cores, the score matrix in the workspace
+ * (ofx_attention_workspace_bytes, 16-byte aligned; slice BH to bound it). */
 size_t ofx_attention_workspace_bytes(int BH, int Nq, int Nk, int D);
 int ofx_attention_f32(const float* q, const float* k, const float* v, const float* bias, long bias_bstride, float* out,
                       int BH, int Nq, int Nk, int D, float scale, void* workspace, size_t workspace_bytes, void* stream);

@@ -5,7 +5,8 @@ The reference cannot run `ldm/` without xformers: both attention modules call
 (ldm/modules/attention.py:314 and :426) on `[batch * heads, tokens, dim_head]` tensors, with an optional additive bias
 built from the flow-guided neighbourhood (:283-311, :392-423).  `memory_efficient_attention` below has that signature
 and those semantics -- softmax(q k^T / sqrt(dim_head) + attn_bias) v -- and runs on the HIP kernels of libofx.so
-(`ofx_attention_f32`: both products on the fp32 matrix cores, exact fp32 softmax).  The top-level `xformers` package of
+(`ofx_attention_f32`: both products on the fp32 matrix cores, exact fp32 softmax; the UNet's head sizes 40 / 64 / 80 /
+128 / 160 take the fused online-softmax kernel of csrc/attn_flash.hip, which keeps the scores on the CU).  The top-level `xformers` package of
 this repository re-exports it, so `import xformers.ops` in the reference resolves here unchanged.
 
 Half / bfloat16 inputs are computed in fp32 and cast back (xformers computes them at reduced precision; fp32 is the

@@ -42,6 +42,11 @@ extern "C" int ofx_conv2d_alpha(const ofx_conv_desc* d, float alpha, void* strea
 // conv.hip: the blocked correlation volume GEMM that also writes pyramid level 1 from its accumulators
 int ofx_conv2d_volpool(const ofx_conv_desc* d, float alpha, float* pool_out, long pool_zs, int wb0, int wb1, int slice1, void* stream);
 
+// attn_flash.hip: fused attention for the UNet's head sizes (no workspace)
+bool ofx_attention_flash_ok(int D);
+int ofx_attention_flash_launch(const float* q, const float* k, const float* v, const float* bias, long bias_bstride, float* out, int BH, int Nq,
+                               int Nk, int D, float scale, hipStream_t s);
+
 // corr.hip / net_misc.hip: internal launchers used by the RAFT engine
 int ofx_local_corr_launch(const float* f1, const float* f2, const float* coords, float* out, long sb, long sn,
                           long sc, long sp, int B, int H1, int W1, int H2, int W2, int C, int N, int r, float scale,

@@ -10,7 +10,8 @@
 //                        and of AttnBlock.forward (model.py:179-203).  Both GEMMs run on the fp32 matrix cores through
 //                        the batched mode of the implicit-GEMM kernel (conv.hip); the score matrix lives in a caller
 //                        workspace (1 GiB for the VAE's 16384-token mid block at 1024x1024: 288 GB of HBM make the
-//                        unfused form the simple and exact one; a fused flash kernel is the next step for the UNet).
+//                        unfused form the simple and exact one).  The UNet's head sizes are routed to the fused kernel of
+//                        attn_flash.hip instead.
 #include "ofx_internal.h"
 
 #include <algorithm>
@@ -249,14 +250,18 @@ int ofx_softmax_rows(float* x, long rows, long ld, int n, float scale, const flo
 // floats of workspace for one call: padded K rows + scores + V^T for `bh` batch-heads at a time
 size_t ofx_attention_workspace_bytes(int BH, int Nq, int Nk, int D) {
     if (BH <= 0 || Nq <= 0 || Nk <= 0 || D <= 0) return 0;
+    if (ofx_attention_flash_ok(D)) return 0;            // fused kernel: the scores never leave the CU
     const long kp = round_up(D, 32), lds = round_up(Nk, 4), vp = round_up(Nk, 32);
     return (size_t)BH * ((size_t)Nk * kp + (size_t)Nq * lds + (size_t)D * vp) * sizeof(float) + 1024;
 }
 
 int ofx_attention_f32(const float* q, const float* k, const float* v, const float* bias, long bias_bstride, float* out, int BH, int Nq, int Nk,
                       int D, float scale, void* workspace, size_t workspace_bytes, void* stream) {
-    OFX_REQUIRE(q && k && v && out && workspace && BH > 0 && Nq > 0 && Nk > 0 && D > 0, OFX_EINVAL);
-    OFX_REQUIRE(D % 4 == 0 && ofx_aligned16(q) && ofx_aligned16(k) && ofx_aligned16(v) && ofx_aligned16(out) && ofx_aligned16(workspace), OFX_EALIGN);
+    OFX_REQUIRE(q && k && v && out && BH > 0 && Nq > 0 && Nk > 0 && D > 0, OFX_EINVAL);
+    OFX_REQUIRE(D % 4 == 0 && ofx_aligned16(q) && ofx_aligned16(k) && ofx_aligned16(v) && ofx_aligned16(out), OFX_EALIGN);
+    if (ofx_attention_flash_ok(D))
+        return ofx_attention_flash_launch(q, k, v, bias, bias_bstride, out, BH, Nq, Nk, D, scale, (hipStream_t)stream);
+    OFX_REQUIRE(workspace && ofx_aligned16(workspace), OFX_EALIGN);
     OFX_REQUIRE(workspace_bytes >= ofx_attention_workspace_bytes(BH, Nq, Nk, D), OFX_ENOMEM);
     hipStream_t s = (hipStream_t)stream;
     const long kp = round_up(D, 32), lds = round_up(Nk, 4), vp = round_up(Nk, 32);

@@ -488,9 +488,9 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, bias: Optional[
             raise RuntimeError("attention: bias must be [Nq,Nk] or [BH,Nq,Nk]")
     scale = float(D) ** -0.5 if scale is None else float(scale)
     L = _lib.lib()
-    one = L.ofx_attention_workspace_bytes(1, Nq, Nk, D)
-    step = max(1, min(BH, int(max_workspace_bytes // max(one, 1))))
-    ws = torch.empty((L.ofx_attention_workspace_bytes(step, Nq, Nk, D),), dtype=torch.uint8, device=q.device)
+    one = L.ofx_attention_workspace_bytes(1, Nq, Nk, D)          # 0: the fused kernel takes this head size, no scores in HBM
+    step = BH if one == 0 else max(1, min(BH, int(max_workspace_bytes // one)))
+    ws = torch.empty((max(16, L.ofx_attention_workspace_bytes(step, Nq, Nk, D)),), dtype=torch.uint8, device=q.device)
     out = torch.empty_like(q)
     for z0 in range(0, BH, step):
         n = min(step, BH - z0)

@@ -27,7 +27,8 @@ def test_groupnorm_and_silu(cuda):
         assert (out_s - ref * torch.sigmoid(ref)).abs().max().item() < 2e-5
 
 
-@pytest.mark.parametrize("BH,Nq,Nk,D", [(3, 50, 77, 40), (2, 96, 96, 80), (1, 130, 130, 512), (5, 33, 7, 160)])
+@pytest.mark.parametrize("BH,Nq,Nk,D", [(3, 50, 77, 40), (2, 96, 96, 80), (1, 130, 130, 512), (5, 33, 7, 160), (2, 70, 45, 48),
+                                        (8, 300, 333, 64), (16, 257, 515, 128), (8, 1000, 1100, 40), (8, 129, 64, 160)])
 def test_attention_matches_the_oracle(cuda, BH, Nq, Nk, D):
     """memory_efficient_attention's shapes: cross attention against 77 text tokens (Nk not a multiple of 4), SD's head
     sizes 40 / 80 / 160, the VAE mid block's single 512-wide head; without bias, with a shared [Nq,Nk] bias and with a
@@ -42,6 +43,26 @@ def test_attention_matches_the_oracle(cuda, BH, Nq, Nk, D):
     # slicing the batch-heads to bound the workspace does not change the result
     out_sliced = ops.attention(q.cuda(), k.cuda(), v.cuda(), None, max_workspace_bytes=1).cpu()
     assert (out_sliced - VO.attention(q, k, v)).abs().max().item() < 2e-5
+
+
+def test_fused_attention_masked_keys_and_large_logits(cuda):
+    """The fused kernel's online softmax: -inf bias entries (masked keys, including whole leading key blocks), logits
+    far from zero (the running maximum must carry the scale), and a row whose every key is masked (NaN, like softmax)."""
+    from sd_animation_optical_flow_amd import ops
+    g = torch.Generator().manual_seed(3)
+    BH, Nq, Nk, D = 8, 200, 150, 40
+    q, k, v = torch.randn((BH, Nq, D), generator=g) * 6, torch.randn((BH, Nk, D), generator=g) * 6, torch.randn((BH, Nk, D), generator=g)
+    bias = torch.zeros((Nq, Nk))
+    bias[:, :70] = float("-inf")                         # the first two 32-key blocks and part of the third
+    bias[torch.rand((Nq, Nk), generator=g) < 0.3] = float("-inf")
+    bias[5, :] = float("-inf")
+    ref = VO.attention(q, k, v, bias)
+    out = ops.attention(q.cuda(), k.cuda(), v.cuda(), bias.cuda()).cpu()
+    assert torch.isnan(out[:, 5]).all() and torch.isnan(ref[:, 5]).all()
+    keep = torch.ones(Nq, dtype=torch.bool)
+    keep[5] = False
+    keep &= ~torch.isinf(bias).all(1)
+    assert (out[:, keep] - ref[:, keep]).abs().max().item() < 5e-5
 
 
 def test_xformers_shim_on_the_device(cuda):
