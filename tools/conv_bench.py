@@ -44,9 +44,13 @@ def run(libpath):
     for name, B, H, W, ci, co, kh, kw, st, _ in SHAPES:
       for tile in TILES:
             x = torch.randn((B, H, W, ci), device="cuda")
+            if os.environ.get("CONV_BENCH_ZERO"):       # power probe: same instruction stream on all-zero operands
+                x.zero_()
             K = kh * kw * ci
             Kp = (K + 31) // 32 * 32
             w = torch.randn((co, Kp), device="cuda") * 0.02
+            if os.environ.get("CONV_BENCH_ZERO"):
+                w.zero_()
             out = torch.empty((B, H // st, W // st, co), device="cuda")
             d = _lib.ConvDesc()
             d.in0, d.ld0, d.c0 = x.data_ptr(), ci, ci
