@@ -76,6 +76,7 @@ struct ConvK {
     float alpha;
     unsigned magic_cin, magic_kw;   // ceil(2^32/d) for d = cin, KW (0 when d == 1): k/d = umulhi(k, magic)
     unsigned kw1_mask;              // all ones when KW == 1 (then tap / KW = tap), else 0
+    int uk;                         // every BK chunk inside one tap and one segment: scalar chunk coordinates (template UK)
     int bytes0, bytes1, bytesw;     // extents of the two input segments and of the weight matrix (per z)
     // kEpiVolPool (correlation volume): level 1 of the pyramid written from the accumulators (see the epilogue)
     float* pool_out; long pool_zs; int pool_wb0, pool_wb1, pool_slice1;
@@ -90,8 +91,12 @@ constexpr int kKAlign = 32;   // packed weights are zero-padded along K to this 
 // two accumulators are added through LDS before the epilogue.  A grid of one workgroup per CU is bound by the
 // latency of its two chunks in flight -- this doubles the loads in flight and the waves per SIMD without
 // touching the tile shape or the epilogue.
-template <int BM, int BN, int WM, int WN, int EPI, bool NORM, int BK, int PREC, int KS = 1, bool SK = false>
-__global__ __launch_bounds__(256 * KS, (BK == 16 && KS == 1) ? (PREC == 3 ? 2 : 3) : 1) void igemm_kernel(const ConvK p) {
+// UK ("uniform K"): every BK-wide chunk lies inside one filter tap and one input segment (cin % BK == 0, c0 % BK == 0).  The tap,
+// its (ky, kx), the segment and the channel base are then the same for the whole wave and live in scalar registers; what is left
+// per staged row is two adds + two compares for the bounds test and one add for the offset -- a third of the vector instructions
+// of the general path, whose issue time is paid in matrix-pipe time (conv experiments).
+template <int BM, int BN, int WM, int WN, int EPI, bool NORM, int BK, int PREC, int KS = 1, bool SK = false, bool UK = false>
+__global__ __launch_bounds__(256 * KS, (BK == 16 && KS == 1) ? (PREC == 3 ? 2 : (PREC == 0 && BM <= 128 && BN <= 128 && !NORM && EPI != OFX_EPI_FLOW) ? 4 : 3) : 1) void igemm_kernel(const ConvK p) {
     constexpr int TM = WM / 32, TN = WN / 32;
     constexpr int WAVES_N = BN / WN;
     constexpr int LDK = BK + 4;               // LDS row stride in floats (144 B / 80 B): conflict-free b128 fragment reads
@@ -196,6 +201,15 @@ __global__ __launch_bounds__(256 * KS, (BK == 16 && KS == 1) ? (PREC == 3 ? 2 : 
     int browb[B_PER];
 #pragma unroll
     for (int i = 0; i < B_PER; ++i) browb[i] = (n0 + r0 + RPG * i) * (p.Kpad * 4) + kq * 16;   // rows past Cout fall off the extent
+    // UK: byte offset of (row pixel, this thread's float4 slot) in each input segment
+    int rowb0[UK ? A_PER : 1], rowb1[UK ? A_PER : 1];
+    if constexpr (UK) {
+#pragma unroll
+        for (int i = 0; i < A_PER; ++i) {
+            rowb0[i] = apix[i] * (p.ld0 * 4) + kq * 16;
+            rowb1[i] = apix[i] * (p.ld1 * 4) + kq * 16;
+        }
+    }
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -229,6 +243,32 @@ __global__ __launch_bounds__(256 * KS, (BK == 16 && KS == 1) ? (PREC == 3 ? 2 : 
     auto offsets = [&](int chunk) __attribute__((always_inline)) {
         // byte offsets of chunk `chunk`: pure VALU, no memory access -> the scheduler interleaves it
         // with the MFMA block that follows it in the steady-state loop body
+        if constexpr (UK) {
+            // wave-uniform chunk coordinates: scalar arithmetic
+            const int k0 = __builtin_amdgcn_readfirstlane(((kbase + chunk * KS) + grp) * BK);
+            const int tap = (int)__umulhi((unsigned)k0, p.magic_cin);
+            const int cch0 = k0 - tap * p.cin;
+            const int ky = (int)(__umulhi((unsigned)tap, p.magic_kw) + ((unsigned)tap & p.kw1_mask));
+            const int kx = tap - ky * p.KW;
+            const bool seg0 = cch0 < p.c0;
+            const int common = (ky * p.Win + kx) * ((seg0 ? p.ld0 : p.ld1) * 4) + (seg0 ? cch0 : cch0 - p.c0) * 4;
+            const bool kval = k0 < p.K;
+            unsigned bits = 0;
+#pragma unroll
+            for (int i = 0; i < A_PER; ++i) {
+                const int iy = a_iy0[i] + ky;
+                const int ix = a_ix0[i] + kx;
+                const bool in = kval & ((unsigned)iy < (unsigned)p.Hin) & ((unsigned)ix < (unsigned)p.Win);
+                bits |= (in ? 1u : 0u) << i;
+                voffa[i] = ((seg0 ? rowb0[i] : rowb1[i]) + common) | (in ? 0 : kOOB);
+            }
+#pragma unroll
+            for (int i = 0; i < B_PER; ++i) voffb[i] = browb[i] + k0 * 4;
+            if (NORM) okbits = (okbits & 0xFFFFu) | (bits << 16);
+            cch_next = cch0 + kq * 4;
+            seg0_next = seg0;
+            return;
+        }
         const int k0 = ((kbase + chunk * KS) + grp) * BK;
         const int k = k0 + kq * 4;
         const int tap = (int)__umulhi((unsigned)k, p.magic_cin);
@@ -727,33 +767,41 @@ __global__ __launch_bounds__(256 * KS, (BK == 16 && KS == 1) ? (PREC == 3 ? 2 : 
     else epilogue(std::false_type{});
 }
 
-template <int BM, int BN, int WM, int WN, int BK, int PREC = 0, int KS = 1, bool SK = false>
-int launch_tile(const ConvK& k, int epi, bool norm, int nz, hipStream_t s) {
+template <int BM, int BN, int WM, int WN, int BK, int PREC, int KS, bool SK, bool UK>
+int launch_tile_uk(const ConvK& k, int epi, bool norm, int nz, hipStream_t s) {
     dim3 grid((unsigned)(k.mtiles * k.ntiles * (k.ksplit > 1 ? k.ksplit : 1)), (unsigned)nz, 1);
     dim3 block(256 * KS, 1, 1);
     switch (epi) {
         case OFX_EPI_PLAIN:
             if (k.act >= OFX_ACT_SIGMOID) {
                 if (norm) return OFX_EINVAL;   // fused-norm producer layers are followed by ReLU / identity only
-                hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, kEpiPlainT, false, BK, PREC, KS, SK>), grid, block, 0, s, k);
+                hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, kEpiPlainT, false, BK, PREC, KS, SK, UK>), grid, block, 0, s, k);
             } else if (norm) {
-                hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, OFX_EPI_PLAIN, true, BK, PREC, KS, SK>), grid, block, 0, s, k);
+                hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, OFX_EPI_PLAIN, true, BK, PREC, KS, SK, UK>), grid, block, 0, s, k);
             } else {
-                hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, OFX_EPI_PLAIN, false, BK, PREC, KS, SK>), grid, block, 0, s, k);
+                hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, OFX_EPI_PLAIN, false, BK, PREC, KS, SK, UK>), grid, block, 0, s, k);
             }
             break;
-        case OFX_EPI_GRU_ZR: hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, OFX_EPI_GRU_ZR, false, BK, PREC, KS, SK>), grid, block, 0, s, k); break;
-        case OFX_EPI_GRU_Q: hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, OFX_EPI_GRU_Q, false, BK, PREC, KS, SK>), grid, block, 0, s, k); break;
-        case OFX_EPI_FLOW: hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, OFX_EPI_FLOW, false, BK, PREC, KS, SK>), grid, block, 0, s, k); break;
+        case OFX_EPI_GRU_ZR: hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, OFX_EPI_GRU_ZR, false, BK, PREC, KS, SK, UK>), grid, block, 0, s, k); break;
+        case OFX_EPI_GRU_Q: hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, OFX_EPI_GRU_Q, false, BK, PREC, KS, SK, UK>), grid, block, 0, s, k); break;
+        case OFX_EPI_FLOW: hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, OFX_EPI_FLOW, false, BK, PREC, KS, SK, UK>), grid, block, 0, s, k); break;
         case kEpiVolPool:
             if constexpr (BM == 128 && BN == 128 && BK == 16 && PREC == 0 && KS == 1 && !SK) {
-                hipLaunchKernelGGL((igemm_kernel<128, 128, 64, 64, kEpiVolPool, false, 16, 0, 1, false>), grid, block, 0, s, k);
+                hipLaunchKernelGGL((igemm_kernel<128, 128, 64, 64, kEpiVolPool, false, 16, 0, 1, false, UK>), grid, block, 0, s, k);
                 break;
             }
             return OFX_EINVAL;
         default: return OFX_EINVAL;
     }
     return ofx_launch_status();
+}
+
+template <int BM, int BN, int WM, int WN, int BK, int PREC = 0, int KS = 1, bool SK = false>
+int launch_tile(const ConvK& k, int epi, bool norm, int nz, hipStream_t s) {
+    if constexpr (PREC == 0 && BN != 192) {   // the 128x192 tile measured 0.8 % slower with scalar chunk coordinates
+        if (k.uk) return launch_tile_uk<BM, BN, WM, WN, BK, PREC, KS, SK, true>(k, epi, norm, nz, s);
+    }
+    return launch_tile_uk<BM, BN, WM, WN, BK, PREC, KS, SK, false>(k, epi, norm, nz, s);
 }
 
 }  // namespace
@@ -952,6 +1000,9 @@ extern "C" int ofx_conv2d_alpha(const ofx_conv_desc* d, float alpha, void* strea
     // chunk wins (+8..20 % at one 512x768 pair).  tile = BK*1e6 + BM*1e3 + BN overrides.
     const int tile_bk = (d->tile % 1000000000) / 1000000;
     const int bk = tile_bk ? tile_bk : ((bn == 32 || bm == 64) ? 32 : 16);
+    // uniform-K fast path: valid for both chunk widths when every channel count is a multiple of 32
+    static const bool no_uk = getenv("OFX_CONV_NO_UK") != nullptr;
+    k.uk = (!no_uk && k.cin % 32 == 0 && (d->c1 == 0 || d->c0 % 32 == 0)) ? 1 : 0;
     if (d->precision != OFX_PREC_FP32) {
         // split-bf16 matrix-core path (opt-in): three tiles; every other choice is mapped onto them (the ragged
         // N of a 96- or 2-channel layer is zero-filled by the descriptors)
