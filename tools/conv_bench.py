@@ -36,6 +36,10 @@ if os.environ.get("CONV_BENCH_B1"):
     ]
 
 
+if os.environ.get("CONV_BENCH_ONLY"):
+    SHAPES = [x for x in SHAPES if os.environ["CONV_BENCH_ONLY"] in x[0]]
+
+
 def run(libpath):
     lib = C.CDLL(libpath)
     lib.ofx_conv2d.restype = C.c_int
