@@ -212,11 +212,9 @@ template <int D, int BK>
 int launch_flash(const FlashArgs& a, hipStream_t s) {
     constexpr int LDK = D + 4, LDV = ((D + 7) / 16) * 16 + 8;
     constexpr size_t lds = 2 * (size_t)(BK * LDK + BK * LDV + 32) * sizeof(float);
-    static bool attr_done = false;                   // > 64 KB of dynamic LDS needs the opt-in once per kernel
-    if (lds > 65536 && !attr_done) {
+    if (lds > 65536) {                               // > 64 KB of dynamic LDS needs the opt-in (per device: set on every launch, it is cheap)
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&flash_attn_kernel<D, BK>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
-        attr_done = true;
     }
     hipLaunchKernelGGL((flash_attn_kernel<D, BK>), dim3((unsigned)(a.BH * a.qtiles)), dim3(256), lds, s, a);
     return ofx_launch_status();
