@@ -25,7 +25,7 @@
 // makes the per-lane ds_read_b128 fragment reads conflict-free; each b128 read feeds four fp32 MFMAs
 // (lane half h supplies k = 8*ks + 4*h + s for s = 0..3 -- the k order inside a chunk is permuted
 // identically for A and B, which leaves the dot product unchanged).  BK = 16 keeps a 128x128 tile at
-// 40 KB of LDS so three workgroups share a CU.
+// 40 KB of LDS: four workgroups (4 x 40 960 B = the CU's 160 KB, <= 128 VGPRs) share a CU; the 128x192 tile, three.
 //
 // Pipeline (one barrier per K-chunk, two LDS buffers, two chunks of global loads in flight):
 //     MFMA block on buf[cur]  ->  commit registers (chunk kt+1) to buf[cur^1]  ->  barrier  ->
@@ -709,7 +709,7 @@ __global__ __launch_bounds__(256 * KS, (BK == 16 && KS == 1) ? (PREC == 3 ? 2 : 
 #pragma unroll
                 for (int ib = 0; ib < TM * (16 / EB); ++ib) {
                     // EB elements per phase: enough loads in flight to cover the latency, few enough live
-                    // registers to keep the kernel at three workgroups per CU
+                    // registers to keep the kernel at its three / four workgroups per CU
                     const int i = ib / (16 / EB), e0 = (ib % (16 / EB)) * EB;
                     float ad[EB], x1[EB], x2[EB];
                     auto row_of = [&](int q) { const int e = e0 + q; return i * 32 + (e & 3) + 8 * (e >> 2); };
@@ -993,7 +993,7 @@ extern "C" int ofx_conv2d_alpha(const ofx_conv_desc* d, float alpha, void* strea
                                                   : "igemm_conv";
     OfxProfScope prof(pname, s);
     prof.flops(2.0 * (double)M * d->Cout * k.K * nz);
-    // BK = 16 keeps LDS at 41 KB and registers under 168 for the 128x128 tile -> 3 workgroups per CU; the
+    // BK = 16 keeps LDS at 40 KB and registers under 128 for the 128x128 tile -> 4 workgroups per CU (3 for 128x192); the
     // extra resident wave per SIMD hides the commit/barrier/issue phases better than a longer chunk does
     // (measured +4..10 % on every shape).  The 64x64 tile is only chosen for grids that under-fill the
     // machine (one workgroup per CU or fewer): there each chunk's load latency is exposed and the longer
