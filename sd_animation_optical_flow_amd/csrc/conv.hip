@@ -222,7 +222,7 @@ __global__ __launch_bounds__(256 * KS, (BK == 16 && KS == 1) ? (PREC == 3 ? 2 : 
     // chunks of this pipeline: grp, grp + KS, ...  (an index past the end addresses k >= K: the A operand
     // reads as zero there, so the surplus iteration of the odd pipeline adds nothing)
     // split-K: this workgroup takes the chunks [kbase, kbase + nk_s) of the K axis
-    const int nk_all = p.Kpad / BK;
+    const int nk_all = (p.K + BK - 1) / BK;       // chunks that hold real k (Kpad rounds K up to 32: up to one all-zero chunk more)
     const int per_split = SK ? (nk_all + p.ksplit - 1) / p.ksplit : nk_all;
     const int kbase = split * per_split;
     const int nk_s = max(0, min(per_split, nk_all - kbase));
