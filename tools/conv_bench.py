@@ -22,6 +22,10 @@ if os.environ.get("CONV_BENCH_N64"):
         ("enc 3x3 64->64 @1/2", 64, 384, 256, 64, 64, 3, 3, 1, 0),
         ("enc 7x7 4->64 s2", 64, 768, 512, 4, 64, 7, 7, 2, 0),
         ("3x3 128->64", 64, 96, 64, 128, 64, 3, 3, 1, 0),
+        ("3x3 256->64", 64, 96, 64, 256, 64, 3, 3, 1, 0),
+        ("3x3 512->64", 64, 96, 64, 512, 64, 3, 3, 1, 0),
+        ("3x3 64->64 @1/8", 64, 96, 64, 64, 64, 3, 3, 1, 0),
+        ("1x1 64->64 @1/2", 64, 384, 256, 64, 64, 1, 1, 1, 0),
     ]
     TILES = [0, 16128064, 16256064]
 if os.environ.get("CONV_BENCH_B1"):
