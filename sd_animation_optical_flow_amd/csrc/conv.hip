@@ -76,7 +76,8 @@ struct ConvK {
     float alpha;
     unsigned magic_cin, magic_kw;   // ceil(2^32/d) for d = cin, KW (0 when d == 1): k/d = umulhi(k, magic)
     unsigned kw1_mask;              // all ones when KW == 1 (then tap / KW = tap), else 0
-    int uk;                         // every BK chunk inside one tap and one segment: scalar chunk coordinates (template UK)
+    int uk;                         // every BK chunk inside one tap and one segment: scalar chunk coordinates (MODE 1)
+    int KH, patch;                  // patch: the layer qualifies for the halo-patch kernel (MODE 2)
     int bytes0, bytes1, bytesw;     // extents of the two input segments and of the weight matrix (per z)
     // kEpiVolPool (correlation volume): level 1 of the pyramid written from the accumulators (see the epilogue)
     float* pool_out; long pool_zs; int pool_wb0, pool_wb1, pool_slice1;
@@ -95,8 +96,18 @@ constexpr int kKAlign = 32;   // packed weights are zero-padded along K to this 
 // its (ky, kx), the segment and the channel base are then the same for the whole wave and live in scalar registers; what is left
 // per staged row is two adds + two compares for the bounds test and one add for the offset -- a third of the vector instructions
 // of the general path, whose issue time is paid in matrix-pipe time (conv experiments).
-template <int BM, int BN, int WM, int WN, int EPI, bool NORM, int BK, int PREC, int KS = 1, bool SK = false, bool UK = false>
+//
+// MODE 2 ("patch"): stride-1 3x3 / 1x5 / 5x1 layers whose map is a whole number of 8x16-pixel patches.  The M tile is such a patch,
+// and instead of gathering an im2col chunk per filter tap, the 16-channel slab of the patch PLUS ITS HALO (10x18 / 8x20 / 12x16
+// pixels) is staged in LDS once and every tap reads its A fragments from it at a shifted row -- the same bytes feed 9 (5) chunks of
+// MFMAs.  The A side then stages 2.8 float4 per thread per 9 chunks instead of 18, its global offsets are constants plus a scalar
+// channel offset, and the input is fetched ~5x less often.  K is walked channel-slab-major (slab, tap) instead of tap-major: the
+// same products in another summation order.  Why it matters: the rate of the general kernel follows the A bytes staged per MFMA
+// (DESIGN.md section 4), which this cuts by the number of taps.
+template <int BM, int BN, int WM, int WN, int EPI, bool NORM, int BK, int PREC, int KS = 1, bool SK = false, int MODE = 0>
 __global__ __launch_bounds__(256 * KS, (BK == 16 && KS == 1) ? (PREC == 3 ? 2 : (PREC == 0 && BM <= 128 && BN <= 128 && !NORM && EPI != OFX_EPI_FLOW) ? 4 : 3) : 1) void igemm_kernel(const ConvK p) {
+    constexpr bool UK = MODE == 1, PATCH = MODE == 2;
+    constexpr int kPatchRows = 192;           // halo patch rows staged per channel slab (12 x 16, 10 x 18 -> 180, 8 x 20 -> 160)
     constexpr int TM = WM / 32, TN = WN / 32;
     constexpr int WAVES_N = BN / WN;
     constexpr int LDK = BK + 4;               // LDS row stride in floats (144 B / 80 B): conflict-free b128 fragment reads
@@ -113,7 +124,7 @@ __global__ __launch_bounds__(256 * KS, (BK == 16 && KS == 1) ? (PREC == 3 ? 2 : 
     static_assert((BM / WM) * (BN / WN) == 4, "4 waves per workgroup");
     static_assert(KS == 1 || KS == 2, "one or two pipelines");
     static_assert(KS == 1 || 2 * STAGE * KS >= 256 * TM * TN * 16, "accumulator exchange must fit the staging buffers");
-    __shared__ __attribute__((aligned(16))) float smem_all[2 * STAGE * KS];
+    __shared__ __attribute__((aligned(16))) float smem_all[PATCH ? (kPatchRows + 2 * BN_ST) * LDK : 2 * STAGE * KS];
     const int grp = KS == 1 ? 0 : (int)(threadIdx.x >> 8);      // pipeline this thread belongs to
     float* const smem = smem_all + grp * (2 * STAGE);
 
@@ -219,6 +230,159 @@ __global__ __launch_bounds__(256 * KS, (BK == 16 && KS == 1) ? (PREC == 3 ? 2 : 
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
+
+    // patch origin of this tile (MODE 2): mt enumerates the 8x16 patches of the batch in raster order
+    int pt_b = 0, pt_y0 = 0, pt_x0 = 0;
+    if constexpr (PATCH) {
+        const int tpr = p.Win >> 4;
+        const int tpi = (p.Hin >> 3) * tpr;
+        pt_b = mt / tpi;
+        const int trem = mt - pt_b * tpi;
+        const int ty = trem / tpr;
+        pt_y0 = ty * 8;
+        pt_x0 = (trem - ty * tpr) * 16;
+    }
+
+    if constexpr (PATCH) {
+        static_assert(!PATCH || (BM == 128 && (WM == 64 || WM == 32) && BK == 16 && PREC == 0 && KS == 1 && !SK), "patch mode: 128-row fp32 tiles");
+        static_assert(!PATCH || (EPI != OFX_EPI_FLOW && EPI != kEpiVolPool), "patch mode: plain / GRU epilogues");
+        typedef int v4i __attribute__((ext_vector_type(4)));
+        const int PWH = 16 + p.KW - 1;                       // halo patch width in pixels
+        const int T = p.KH * p.KW;
+        const int CB = p.cin >> 4;
+        float* const Apatch = smem_all;                      // [kPatchRows][LDK]
+        float* const Bst = smem_all + kPatchRows * LDK;      // two stages of [BN_ST][LDK]
+        constexpr int BSTAGE = BN_ST * LDK;
+        // the three (row, float4 slot) pairs this thread stages per slab; rows permuted like r0 (conflict-free ds_write_b128)
+        int avo0[3], avo1[3];
+        int alds0 = 0;                                       // slot q sits 64 rows below slot 0 (the row permutation keeps j / 16)
+        unsigned aval = 0;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            const int j = (tid + 256 * q) >> 2;
+            const int row = (j & 3) * 4 + ((j >> 2) & 3) + (j >> 4) * 16;
+            const int hy = row / PWH, hx = row - hy * PWH;
+            const int gy = pt_y0 - p.padH + hy, gx = pt_x0 - p.padW + hx;
+            const bool ok = row < (8 + p.KH - 1) * PWH && (unsigned)gy < (unsigned)p.Hin && (unsigned)gx < (unsigned)p.Win;
+            const int pix = (pt_b * p.Hin + gy) * p.Win + gx;
+            avo0[q] = ok ? pix * (p.ld0 * 4) + kq * 16 : kOOB;
+            avo1[q] = ok ? pix * (p.ld1 * 4) + kq * 16 : kOOB;
+            if (q == 0) alds0 = row * LDK + kq * 4;
+            aval |= (ok ? 1u : 0u) << q;
+        }
+        const int frow = lane & 31, fk = (lane >> 5) * 4;
+        int afr[TM], bfr[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int r = wm * WM + i * 32 + frow;
+            afr[i] = ((r >> 4) * PWH + (r & 15)) * LDK + fk;
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) bfr[j] = (wn * WN + j * 32 + frow) * LDK + fk;
+
+        float4 pa[3];
+        float4 pmu = make_float4(0.f, 0.f, 0.f, 0.f), prs = pmu;
+        float4 rb0 = make_float4(0.f, 0.f, 0.f, 0.f), rb1 = rb0, rb2 = rb0, rb3 = rb0;
+        auto a_issue = [&](int cb) __attribute__((always_inline)) {
+            const int c = cb << 4;
+            const bool s0 = c < p.c0;                        // wave-uniform
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(s0 ? in0 : in1s), (short)0, s0 ? p.bytes0 : bytes1s, 0x00020000);
+            const int so = (s0 ? c : c - p.c0) * 4;
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                v4i t = __builtin_amdgcn_raw_buffer_load_b128(rs, s0 ? avo0[q] : avo1[q], so, 0);
+                pa[q] = *reinterpret_cast<float4*>(&t);
+            }
+            if (NORM) {
+                pmu = *reinterpret_cast<const float4*>(p.nmean + (long)pt_b * p.c0 + c + kq * 4);
+                prs = *reinterpret_cast<const float4*>(p.nrstd + (long)pt_b * p.c0 + c + kq * 4);
+            }
+        };
+        auto a_commit = [&]() __attribute__((always_inline)) {
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                float4 v = pa[q];
+                if (NORM) {
+                    v.x = fmaxf((v.x - pmu.x) * prs.x, 0.f);
+                    v.y = fmaxf((v.y - pmu.y) * prs.y, 0.f);
+                    v.z = fmaxf((v.z - pmu.z) * prs.z, 0.f);
+                    v.w = fmaxf((v.w - pmu.w) * prs.w, 0.f);
+                    if (!((aval >> q) & 1u)) v = make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+                *reinterpret_cast<float4*>(&Apatch[alds0 + q * 64 * LDK]) = v;
+            }
+        };
+        // weight chunks are issued two ahead of the one being multiplied: (itap, icb) is the next one to issue
+        int itap = 0, icb = 0;
+        auto b_issue = [&]() __attribute__((always_inline)) {
+            const int so = (itap * p.cin + (icb << 4)) * 4;
+#define OFX_B_ISSUE(i) \
+    if constexpr (B_PER > i) { v4i t = __builtin_amdgcn_raw_buffer_load_b128(rsrcw, browb[i], so, 0); rb##i = *reinterpret_cast<float4*>(&t); }
+            OFX_B_ISSUE(0) OFX_B_ISSUE(1) OFX_B_ISSUE(2) OFX_B_ISSUE(3)
+#undef OFX_B_ISSUE
+            if (icb + 1 < CB || itap + 1 < T) {              // past the last chunk: keep re-issuing it (never multiplied)
+                if (++itap == T) { itap = 0; ++icb; }
+            }
+        };
+        auto b_commit = [&](float* Bs) __attribute__((always_inline)) {
+#define OFX_B_COMMIT(i) \
+    if constexpr (B_PER > i) *reinterpret_cast<float4*>(&Bs[(r0 + RPG * i) * LDK + kq * 4]) = rb##i;
+            OFX_B_COMMIT(0) OFX_B_COMMIT(1) OFX_B_COMMIT(2) OFX_B_COMMIT(3)
+#undef OFX_B_COMMIT
+        };
+
+        auto step = [&](int c, int ky, int kx) __attribute__((always_inline)) {
+            const float* As = Apatch + (ky * PWH + kx) * LDK;
+            const float* Bs = Bst + (c & 1) * BSTAGE;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                float4 fa[TM], fb[TN];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) fa[i] = *reinterpret_cast<const float4*>(&As[afr[i] + ks * 8]);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) fb[j] = *reinterpret_cast<const float4*>(&Bs[bfr[j] + ks * 8]);
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].x, fb[j].x, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].y, fb[j].y, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].z, fb[j].z, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].w, fb[j].w, acc[i][j], 0, 0, 0);
+                    }
+            }
+            b_commit(Bst + ((c + 1) & 1) * BSTAGE);          // chunk c + 1 has had this MFMA block to land
+            __syncthreads();
+            b_issue();                                       // chunk c + 2
+            __builtin_amdgcn_sched_barrier(0);
+        };
+
+        a_issue(0);
+        b_issue();
+        a_commit();
+        b_commit(Bst);
+        __syncthreads();
+        b_issue();
+        // Per slab: T - 1 plain steps, then the last tap peeled -- the next slab's three loads per thread are issued in front of it
+        // and committed behind it, so their registers are live for one step only (held across the whole slab they pushed the
+        // 128x128 tile into scratch).  The barrier that ends the last step also says every wave is done reading the patch.
+        int c = 0;
+        for (int cb = 0; cb < CB; ++cb) {
+            int ky = 0, kx = 0;
+            for (int tap = 0; tap < T - 1; ++tap, ++c) {
+                step(c, ky, kx);
+                if (++kx == p.KW) { kx = 0; ++ky; }
+            }
+            const bool more = cb + 1 < CB;                   // wave-uniform
+            if (more) a_issue(cb + 1);
+            step(c, ky, kx);
+            ++c;
+            if (more) {
+                a_commit();
+                __syncthreads();
+            }
+        }
+    } else {
     // chunks of this pipeline: grp, grp + KS, ...  (an index past the end addresses k >= K: the A operand
     // reads as zero there, so the surplus iteration of the odd pipeline adds nothing)
     // split-K: this workgroup takes the chunks [kbase, kbase + nk_s) of the K axis
@@ -525,6 +689,7 @@ __global__ __launch_bounds__(256 * KS, (BK == 16 && KS == 1) ? (PREC == 3 ? 2 : 
         issue();
         __builtin_amdgcn_sched_barrier(0);   // keep the loads ahead of the next MFMA block
     }
+    }   // !PATCH
 
     if constexpr (KS == 2) {
         // add the two pipelines' accumulators: the odd one parks its tile in LDS and retires
@@ -619,8 +784,10 @@ __global__ __launch_bounds__(256 * KS, (BK == 16 && KS == 1) ? (PREC == 3 ? 2 : 
     };
     const bool has_add = p.addend != nullptr;
     const bool has_res = p.res != nullptr;
-    const int mb0 = m0 + wm * WM + 4 * (lane >> 5);       // first row of this thread
-    const int lim = Mrows - mb0;                          // relative rows r < lim exist
+    // first row of this thread.  Patch mode: tile row r is pixel (r / 16, r % 16) of the patch, so the thread's first row is a
+    // pixel index and the step from it to row_of(q) is srow(q) pixels (wave-uniform: it goes into the scalar offset as before)
+    const int mb0 = PATCH ? (pt_b * p.Hin + pt_y0 + ((wm * WM) >> 4)) * p.Win + pt_x0 + 4 * (lane >> 5) : m0 + wm * WM + 4 * (lane >> 5);
+    const int lim = PATCH ? 0x7fffffff : Mrows - mb0;     // relative rows r < lim exist (a patch is always whole)
     constexpr int EB = EPI == OFX_EPI_GRU_Q ? 4 : 8;
     // Control flow is kept out of the element loops: the optional reads are decided once per batch of EB
     // elements, ReLU / the residual ReLU are a max against 0 or -FLT_MAX, the transcendental activations of the
@@ -713,23 +880,27 @@ __global__ __launch_bounds__(256 * KS, (BK == 16 && KS == 1) ? (PREC == 3 ? 2 : 
                     const int i = ib / (16 / EB), e0 = (ib % (16 / EB)) * EB;
                     float ad[EB], x1[EB], x2[EB];
                     auto row_of = [&](int q) { const int e = e0 + q; return i * 32 + (e & 3) + 8 * (e >> 2); };
+                    auto srow = [&](int q) {
+                        const int e = e0 + q;
+                        return PATCH ? (2 * i + (e >> 3)) * p.Win + (e & 3) + 8 * ((e >> 2) & 1) : row_of(q);
+                    };
                     auto mask_of = [&](int r) { return FULL ? 0 : (r < lim ? 0 : kOOB); };
                     if (has_add) {
 #pragma unroll
-                        for (int q = 0; q < EB; ++q) ad[q] = ldf(rs_add, vo_add | mask_of(row_of(q)), row_of(q) * p.ldadd * 4);
+                        for (int q = 0; q < EB; ++q) ad[q] = ldf(rs_add, vo_add | mask_of(row_of(q)), srow(q) * p.ldadd * 4);
                     } else {
 #pragma unroll
                         for (int q = 0; q < EB; ++q) ad[q] = 0.0f;
                     }
                     if (need1) {
 #pragma unroll
-                        for (int q = 0; q < EB; ++q) x1[q] = ldf(rs_1, vo_1 | mask_of(row_of(q)), row_of(q) * ld1 * 4);
+                        for (int q = 0; q < EB; ++q) x1[q] = ldf(rs_1, vo_1 | mask_of(row_of(q)), srow(q) * ld1 * 4);
                     } else {
 #pragma unroll
                         for (int q = 0; q < EB; ++q) x1[q] = EPK == OFX_EPI_GRU_ZR ? 1.0f : 0.0f;   // z half: no r*h product
                     }
 #pragma unroll
-                    for (int q = 0; q < EB; ++q) x2[q] = EPK == OFX_EPI_GRU_Q ? ldf(rs_h, vo_h | mask_of(row_of(q)), row_of(q) * p.ldh * 4) : 0.0f;
+                    for (int q = 0; q < EB; ++q) x2[q] = EPK == OFX_EPI_GRU_Q ? ldf(rs_h, vo_h | mask_of(row_of(q)), srow(q) * p.ldh * 4) : 0.0f;
                     float v[EB];
 #pragma unroll
                     for (int q = 0; q < EB; ++q) v[q] = acc[i][j][e0 + q] * sc + sh + ad[q];
@@ -752,22 +923,22 @@ __global__ __launch_bounds__(256 * KS, (BK == 16 && KS == 1) ? (PREC == 3 ? 2 : 
                         } else {
                             v[q] = (1.0f - x1[q]) * x2[q] + x1[q] * ofx_tanh(v[q]);
                         }
-                        stf(v[q], rs_w, vo_w | mask_of(row_of(q)), row_of(q) * ldw * 4);
+                        stf(v[q], rs_w, vo_w | mask_of(row_of(q)), srow(q) * ldw * 4);
                         if constexpr (VOLPOOL) {
                             const float s1 = v[q] + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v[q]), 0xB1, 0xF, 0xF, false));   // quad_perm [1,0,3,2]: lane ^ 1
                             const float s2 = s1 + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(s1), 0x128, 0xF, 0xF, false));    // row_ror:8: lane ^ 8
-                            stf(s2 * 0.25f, rs_p, vo_p | mask_of(row_of(q)), row_of(q) * p.pool_slice1 * 4);
+                            stf(s2 * 0.25f, rs_p, vo_p | mask_of(row_of(q)), srow(q) * p.pool_slice1 * 4);
                         }
                     }
                 }
             }
         }
     };
-    if (m0 + BM <= Mrows) epilogue(std::true_type{});
+    if (PATCH || m0 + BM <= Mrows) epilogue(std::true_type{});
     else epilogue(std::false_type{});
 }
 
-template <int BM, int BN, int WM, int WN, int BK, int PREC, int KS, bool SK, bool UK>
+template <int BM, int BN, int WM, int WN, int BK, int PREC, int KS, bool SK, int UK>
 int launch_tile_uk(const ConvK& k, int epi, bool norm, int nz, hipStream_t s) {
     dim3 grid((unsigned)(k.mtiles * k.ntiles * (k.ksplit > 1 ? k.ksplit : 1)), (unsigned)nz, 1);
     dim3 block(256 * KS, 1, 1);
@@ -784,9 +955,14 @@ int launch_tile_uk(const ConvK& k, int epi, bool norm, int nz, hipStream_t s) {
             break;
         case OFX_EPI_GRU_ZR: hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, OFX_EPI_GRU_ZR, false, BK, PREC, KS, SK, UK>), grid, block, 0, s, k); break;
         case OFX_EPI_GRU_Q: hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, OFX_EPI_GRU_Q, false, BK, PREC, KS, SK, UK>), grid, block, 0, s, k); break;
-        case OFX_EPI_FLOW: hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, OFX_EPI_FLOW, false, BK, PREC, KS, SK, UK>), grid, block, 0, s, k); break;
+        case OFX_EPI_FLOW:
+            if constexpr (UK != 2) {
+                hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, OFX_EPI_FLOW, false, BK, PREC, KS, SK, UK>), grid, block, 0, s, k);
+                break;
+            }
+            return OFX_EINVAL;
         case kEpiVolPool:
-            if constexpr (BM == 128 && BN == 128 && BK == 16 && PREC == 0 && KS == 1 && !SK) {
+            if constexpr (BM == 128 && BN == 128 && BK == 16 && PREC == 0 && KS == 1 && !SK && UK != 2) {
                 hipLaunchKernelGGL((igemm_kernel<128, 128, 64, 64, kEpiVolPool, false, 16, 0, 1, false, UK>), grid, block, 0, s, k);
                 break;
             }
@@ -798,10 +974,13 @@ int launch_tile_uk(const ConvK& k, int epi, bool norm, int nz, hipStream_t s) {
 
 template <int BM, int BN, int WM, int WN, int BK, int PREC = 0, int KS = 1, bool SK = false>
 int launch_tile(const ConvK& k, int epi, bool norm, int nz, hipStream_t s) {
-    if constexpr (PREC == 0 && BN != 192) {   // the 128x192 tile measured 0.8 % slower with scalar chunk coordinates
-        if (k.uk) return launch_tile_uk<BM, BN, WM, WN, BK, PREC, KS, SK, true>(k, epi, norm, nz, s);
+    if constexpr (PREC == 0 && BM == 128 && BK == 16 && KS == 1 && !SK && (BN == 64 || BN == 96 || BN == 128 || BN == 192)) {
+        if (k.patch && epi != OFX_EPI_FLOW && epi != kEpiVolPool) return launch_tile_uk<BM, BN, WM, WN, BK, PREC, KS, SK, 2>(k, epi, norm, nz, s);
     }
-    return launch_tile_uk<BM, BN, WM, WN, BK, PREC, KS, SK, false>(k, epi, norm, nz, s);
+    if constexpr (PREC == 0 && BN != 192) {   // the 128x192 tile measured 0.8 % slower with scalar chunk coordinates
+        if (k.uk) return launch_tile_uk<BM, BN, WM, WN, BK, PREC, KS, SK, 1>(k, epi, norm, nz, s);
+    }
+    return launch_tile_uk<BM, BN, WM, WN, BK, PREC, KS, SK, 0>(k, epi, norm, nz, s);
 }
 
 }  // namespace
@@ -1003,6 +1182,15 @@ extern "C" int ofx_conv2d_alpha(const ofx_conv_desc* d, float alpha, void* strea
     // uniform-K fast path: valid for both chunk widths when every channel count is a multiple of 32
     static const bool no_uk = getenv("OFX_CONV_NO_UK") != nullptr;
     k.uk = (!no_uk && k.cin % 32 == 0 && (d->c1 == 0 || d->c0 % 32 == 0)) ? 1 : 0;
+    // halo-patch kernel: stride-1 3x3 / 1x5 / 5x1, "same" padding, the map a whole number of 8x16 patches, whole 16-channel slabs
+    static const bool no_patch = getenv("OFX_CONV_NO_PATCH") != nullptr;
+    const bool shape_ok = (d->KH == 3 && d->KW == 3) || (d->KH == 1 && d->KW == 5) || (d->KH == 5 && d->KW == 1);
+    k.KH = d->KH;
+    k.patch = (!no_patch && d->precision == OFX_PREC_FP32 && shape_ok && d->stride == 1 && d->padH == d->KH / 2 && d->padW == d->KW / 2 &&
+               d->Hin == d->Hout && d->Win == d->Wout && d->Hin % 8 == 0 && d->Win % 16 == 0 && k.cin % 16 == 0 &&
+               (d->c1 == 0 || d->c0 % 16 == 0) && (!d->nmean || d->c1 == 0) && nz == 1 && bm == 128 && bk == 16 && M % 128 == 0)
+                  ? 1 : 0;
+    if (k.patch) k.ksplit = 1;
     if (d->precision != OFX_PREC_FP32) {
         // split-bf16 matrix-core path (opt-in): three tiles; every other choice is mapped onto them (the ragged
         // N of a 96- or 2-channel layer is zero-filled by the descriptors)

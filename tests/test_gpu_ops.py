@@ -161,6 +161,47 @@ def test_conv2d_bf16x6_mode_is_fp32_accurate(cuda, case):
     assert not torch.equal(out6, out32)                      # a different summation, not the fp32 kernel by accident
 
 
+@pytest.mark.parametrize("case", [  # B, H, W, c0, c1, cout, kh, kw, tile
+    (2, 16, 32, 64, 0, 64, 3, 3, 16128064), (1, 24, 48, 256, 0, 192, 3, 3, 16128192), (2, 8, 16, 128, 256, 256, 1, 5, 16128128),
+    (1, 40, 16, 128, 128, 128, 5, 1, 16128128), (3, 8, 32, 96, 0, 96, 3, 3, 16128096), (1, 64, 96, 128, 0, 256, 3, 3, 16128128),
+    (1, 16, 16, 16, 0, 70, 3, 3, 16128128)])
+def test_conv2d_halo_patch_kernel(cuda, case):
+    """The halo-patch instantiation (stride-1 3x3 / 1x5 / 5x1 on maps made of whole 8x16 patches; forced here through the
+    128-row tile override, the executor reaches it by itself at batch size) against F.conv2d: borders, every tile width, one
+    and two input segments, addend / residual / scale epilogue, a ragged N; and against the general kernel (OFX_CONV_NO_PATCH
+    is read once per process, so the comparison is with the 64x64 tile, which never takes the patch path)."""
+    ops = _ops()
+    B, H, W, c0, c1, co, kh, kw, tile = case
+    g = torch.Generator().manual_seed(sum(case))
+    xa = torch.randn((B, c0, H, W), generator=g)
+    xb = torch.randn((B, c1, H, W), generator=g) if c1 else None
+    ci = c0 + c1
+    w = torch.randn((co, ci, kh, kw), generator=g) / np.sqrt(ci * kh * kw)
+    sc = torch.rand((co,), generator=g) + 0.5
+    sh = torch.randn((co,), generator=g)
+    res = torch.randn((B, co, H, W), generator=g)
+    xin = xa if xb is None else torch.cat([xa, xb], 1)
+    y = F.conv2d(xin.double(), w.double(), None, padding=(kh // 2, kw // 2)) * sc.double().view(1, -1, 1, 1) + sh.double().view(1, -1, 1, 1)
+    ref = torch.relu(torch.relu(y) + res.double()).float()
+    kwargs = dict(shift=sh.cuda(), scale=sc.cuda(), act="relu", x2=None if xb is None else nhwc(xb), res=nhwc(res))
+    out = ops.conv2d_nhwc(nhwc(xa), ops.pack_conv_weight(w).cuda(), kh, kw, co, tile=tile, **kwargs)
+    assert (nchw(out) - ref).abs().max().item() < 2e-5
+    gen = ops.conv2d_nhwc(nhwc(xa), ops.pack_conv_weight(w).cuda(), kh, kw, co, tile=32064064, **kwargs)
+    assert (nchw(gen) - ref).abs().max().item() < 2e-5
+    assert not torch.equal(out, gen) or ci <= 16            # another summation order: the patch path really ran
+
+
+def test_conv2d_halo_patch_with_fused_instance_norm(cuda):
+    ops = _ops()
+    g = torch.Generator().manual_seed(12)
+    raw = torch.randn((2, 64, 16, 32), generator=g) * 2 + 0.5
+    w = torch.randn((64, 64, 3, 3), generator=g) / 24
+    mean, rstd = ops.inorm_stats(nhwc(raw))
+    ref = F.conv2d(torch.relu(F.instance_norm(raw)).double(), w.double(), None, padding=1).float()
+    out = ops.conv2d_nhwc(nhwc(raw), ops.pack_conv_weight(w).cuda(), 3, 3, 64, nmean=mean, nrstd=rstd, tile=16128064)
+    assert (nchw(out) - ref).abs().max().item() < 5e-5
+
+
 def test_conv2d_two_segments_residual_and_scale(cuda):
     ops = _ops()
     g = torch.Generator().manual_seed(3)

@@ -15,8 +15,6 @@ SHAPES = [  # name, B, H, W, Cin, Cout, kh, kw, stride, tile
     ("enc 3x3 96->96 @1/4", 16, 192, 128, 96, 96, 3, 3, 1, 0),
 ]
 TILES = [0, 128128, 16128128, 128064, 16128064, 64064, 16064064]
-if os.environ.get('CONV_BENCH_TILES'):
-    TILES = [int(t) for t in os.environ['CONV_BENCH_TILES'].split(',')]
 if os.environ.get("CONV_BENCH_N64"):
     SHAPES = [
         ("enc 3x3 64->64 @1/2", 64, 384, 256, 64, 64, 3, 3, 1, 0),
@@ -40,6 +38,8 @@ if os.environ.get("CONV_BENCH_B1"):
     ]
 
 
+if os.environ.get('CONV_BENCH_TILES'):
+    TILES = [int(t) for t in os.environ['CONV_BENCH_TILES'].split(',')]
 if os.environ.get("CONV_BENCH_ONLY"):
     SHAPES = [x for x in SHAPES if os.environ["CONV_BENCH_ONLY"] in x[0]]
 
