@@ -107,7 +107,10 @@ constexpr int kKAlign = 32;   // packed weights are zero-padded along K to this 
 template <int BM, int BN, int WM, int WN, int EPI, bool NORM, int BK, int PREC, int KS = 1, bool SK = false, int MODE = 0>
 __global__ __launch_bounds__(256 * KS, (BK == 16 && KS == 1) ? (PREC == 3 ? 2 : (PREC == 0 && BM <= 128 && BN <= 128 && !NORM && EPI != OFX_EPI_FLOW) ? 4 : 3) : 1) void igemm_kernel(const ConvK p) {
     constexpr bool UK = MODE == 1, PATCH = MODE == 2;
-    constexpr int kPatchRows = 192;           // halo patch rows staged per channel slab (12 x 16, 10 x 18 -> 180, 8 x 20 -> 160)
+    // halo patch rows staged per channel slab, rounded up to whole groups of 16: 8x16 patches 12 x 16 / 10 x 18 / 8 x 20 -> 192,
+    // 8x8 patches (the 64-row tile) 12 x 8 / 10 x 10 / 8 x 12 -> 112
+    constexpr int kPatchRows = BM == 128 ? 192 : 112;
+    constexpr int kPW = BM == 128 ? 16 : 8;   // patch width in pixels (its height is 8)
     constexpr int TM = WM / 32, TN = WN / 32;
     constexpr int WAVES_N = BN / WN;
     constexpr int LDK = BK + 4;               // LDS row stride in floats (144 B / 80 B): conflict-free b128 fragment reads
@@ -234,36 +237,43 @@ __global__ __launch_bounds__(256 * KS, (BK == 16 && KS == 1) ? (PREC == 3 ? 2 : 
     // patch origin of this tile (MODE 2): mt enumerates the 8x16 patches of the batch in raster order
     int pt_b = 0, pt_y0 = 0, pt_x0 = 0;
     if constexpr (PATCH) {
-        const int tpr = p.Win >> 4;
+        const int tpr = p.Win / kPW;
         const int tpi = (p.Hin >> 3) * tpr;
         pt_b = mt / tpi;
         const int trem = mt - pt_b * tpi;
         const int ty = trem / tpr;
         pt_y0 = ty * 8;
-        pt_x0 = (trem - ty * tpr) * 16;
+        pt_x0 = (trem - ty * tpr) * kPW;
     }
 
     if constexpr (PATCH) {
-        static_assert(!PATCH || (BM == 128 && (WM == 64 || WM == 32) && BK == 16 && PREC == 0 && KS == 1 && !SK), "patch mode: 128-row fp32 tiles");
+        static_assert(!PATCH || (PREC == 0 && KS == 1 && ((BM == 128 && (WM == 64 || WM == 32) && BK == 16 && !SK) || (BM == 64 && WM == 32 && BK == 32))),
+                      "patch mode: 128-row tiles with 16-channel slabs, or the 64x64 small-grid tile with 32-channel slabs (split-K allowed)");
         static_assert(!PATCH || (EPI != OFX_EPI_FLOW && EPI != kEpiVolPool), "patch mode: plain / GRU epilogues");
         typedef int v4i __attribute__((ext_vector_type(4)));
-        const int PWH = 16 + p.KW - 1;                       // halo patch width in pixels
+        const int PWH = kPW + p.KW - 1;                      // halo patch width in pixels
         const int T = p.KH * p.KW;
-        const int CB = p.cin >> 4;
+        const int CBall = p.cin / BK;                        // channel slabs of BK channels
+        // split-K: this workgroup takes the slabs [cb_lo, cb_hi) -- possibly none: it then parks a zero tile
+        const int cb_per = SK ? (CBall + p.ksplit - 1) / p.ksplit : CBall;
+        const int cb_lo = SK ? min(split * cb_per, CBall) : 0;
+        const int CB = SK ? min(cb_lo + cb_per, CBall) : CBall;   // exclusive upper bound
         float* const Apatch = smem_all;                      // [kPatchRows][LDK]
         float* const Bst = smem_all + kPatchRows * LDK;      // two stages of [BN_ST][LDK]
         constexpr int BSTAGE = BN_ST * LDK;
-        // the three (row, float4 slot) pairs this thread stages per slab; rows permuted like r0 (conflict-free ds_write_b128)
-        int avo0[3], avo1[3];
-        int alds0 = 0;                                       // slot q sits 64 rows below slot 0 (the row permutation keeps j / 16)
+        // the (row, float4 slot) pairs this thread stages per slab; rows permuted like r0 (conflict-free ds_write_b128)
+        constexpr int NSLOT = (kPatchRows * QPR + 255) / 256;
+        constexpr int SROWS = 256 / QPR;                     // rows between a thread's consecutive slots
+        int avo0[NSLOT], avo1[NSLOT];
+        int alds0 = 0;                                       // slot q sits q * SROWS rows below slot 0 (the row permutation keeps j / 16)
         unsigned aval = 0;
 #pragma unroll
-        for (int q = 0; q < 3; ++q) {
-            const int j = (tid + 256 * q) >> 2;
-            const int row = (j & 3) * 4 + ((j >> 2) & 3) + (j >> 4) * 16;
+        for (int q = 0; q < NSLOT; ++q) {
+            const int j = tid / QPR + SROWS * q;
+            const int row = (j % kG) * kS + (j / kG) % kS + (j / (kG * kS)) * (kG * kS);
             const int hy = row / PWH, hx = row - hy * PWH;
             const int gy = pt_y0 - p.padH + hy, gx = pt_x0 - p.padW + hx;
-            const bool ok = row < (8 + p.KH - 1) * PWH && (unsigned)gy < (unsigned)p.Hin && (unsigned)gx < (unsigned)p.Win;
+            const bool ok = j < kPatchRows && row < (8 + p.KH - 1) * PWH && (unsigned)gy < (unsigned)p.Hin && (unsigned)gx < (unsigned)p.Win;
             const int pix = (pt_b * p.Hin + gy) * p.Win + gx;
             avo0[q] = ok ? pix * (p.ld0 * 4) + kq * 16 : kOOB;
             avo1[q] = ok ? pix * (p.ld1 * 4) + kq * 16 : kOOB;
@@ -275,21 +285,21 @@ __global__ __launch_bounds__(256 * KS, (BK == 16 && KS == 1) ? (PREC == 3 ? 2 : 
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
             const int r = wm * WM + i * 32 + frow;
-            afr[i] = ((r >> 4) * PWH + (r & 15)) * LDK + fk;
+            afr[i] = ((r / kPW) * PWH + (r % kPW)) * LDK + fk;
         }
 #pragma unroll
         for (int j = 0; j < TN; ++j) bfr[j] = (wn * WN + j * 32 + frow) * LDK + fk;
 
-        float4 pa[3];
+        float4 pa[NSLOT];
         float4 pmu = make_float4(0.f, 0.f, 0.f, 0.f), prs = pmu;
         float4 rb0 = make_float4(0.f, 0.f, 0.f, 0.f), rb1 = rb0, rb2 = rb0, rb3 = rb0;
         auto a_issue = [&](int cb) __attribute__((always_inline)) {
-            const int c = cb << 4;
+            const int c = cb * BK;
             const bool s0 = c < p.c0;                        // wave-uniform
             const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(s0 ? in0 : in1s), (short)0, s0 ? p.bytes0 : bytes1s, 0x00020000);
             const int so = (s0 ? c : c - p.c0) * 4;
 #pragma unroll
-            for (int q = 0; q < 3; ++q) {
+            for (int q = 0; q < NSLOT; ++q) {
                 v4i t = __builtin_amdgcn_raw_buffer_load_b128(rs, s0 ? avo0[q] : avo1[q], so, 0);
                 pa[q] = *reinterpret_cast<float4*>(&t);
             }
@@ -300,7 +310,8 @@ __global__ __launch_bounds__(256 * KS, (BK == 16 && KS == 1) ? (PREC == 3 ? 2 : 
         };
         auto a_commit = [&]() __attribute__((always_inline)) {
 #pragma unroll
-            for (int q = 0; q < 3; ++q) {
+            for (int q = 0; q < NSLOT; ++q) {
+                if (NSLOT * 256 > kPatchRows * QPR && q == NSLOT - 1 && tid / QPR + SROWS * q >= kPatchRows) break;   // beyond the patch buffer
                 float4 v = pa[q];
                 if (NORM) {
                     v.x = fmaxf((v.x - pmu.x) * prs.x, 0.f);
@@ -309,13 +320,13 @@ __global__ __launch_bounds__(256 * KS, (BK == 16 && KS == 1) ? (PREC == 3 ? 2 : 
                     v.w = fmaxf((v.w - pmu.w) * prs.w, 0.f);
                     if (!((aval >> q) & 1u)) v = make_float4(0.f, 0.f, 0.f, 0.f);
                 }
-                *reinterpret_cast<float4*>(&Apatch[alds0 + q * 64 * LDK]) = v;
+                *reinterpret_cast<float4*>(&Apatch[alds0 + q * SROWS * LDK]) = v;
             }
         };
         // weight chunks are issued two ahead of the one being multiplied: (itap, icb) is the next one to issue
-        int itap = 0, icb = 0;
+        int itap = 0, icb = cb_lo;
         auto b_issue = [&]() __attribute__((always_inline)) {
-            const int so = (itap * p.cin + (icb << 4)) * 4;
+            const int so = (itap * p.cin + icb * BK) * 4;
 #define OFX_B_ISSUE(i) \
     if constexpr (B_PER > i) { v4i t = __builtin_amdgcn_raw_buffer_load_b128(rsrcw, browb[i], so, 0); rb##i = *reinterpret_cast<float4*>(&t); }
             OFX_B_ISSUE(0) OFX_B_ISSUE(1) OFX_B_ISSUE(2) OFX_B_ISSUE(3)
@@ -335,7 +346,7 @@ __global__ __launch_bounds__(256 * KS, (BK == 16 && KS == 1) ? (PREC == 3 ? 2 : 
             const float* As = Apatch + (ky * PWH + kx) * LDK;
             const float* Bs = Bst + (c & 1) * BSTAGE;
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
+            for (int ks = 0; ks < BK / 8; ++ks) {
                 float4 fa[TM], fb[TN];
 #pragma unroll
                 for (int i = 0; i < TM; ++i) fa[i] = *reinterpret_cast<const float4*>(&As[afr[i] + ks * 8]);
@@ -357,7 +368,8 @@ __global__ __launch_bounds__(256 * KS, (BK == 16 && KS == 1) ? (PREC == 3 ? 2 : 
             __builtin_amdgcn_sched_barrier(0);
         };
 
-        a_issue(0);
+        if (cb_lo < CB) {
+        a_issue(cb_lo);
         b_issue();
         a_commit();
         b_commit(Bst);
@@ -367,7 +379,7 @@ __global__ __launch_bounds__(256 * KS, (BK == 16 && KS == 1) ? (PREC == 3 ? 2 : 
         // and committed behind it, so their registers are live for one step only (held across the whole slab they pushed the
         // 128x128 tile into scratch).  The barrier that ends the last step also says every wave is done reading the patch.
         int c = 0;
-        for (int cb = 0; cb < CB; ++cb) {
+        for (int cb = cb_lo; cb < CB; ++cb) {
             int ky = 0, kx = 0;
             for (int tap = 0; tap < T - 1; ++tap, ++c) {
                 step(c, ky, kx);
@@ -382,6 +394,7 @@ __global__ __launch_bounds__(256 * KS, (BK == 16 && KS == 1) ? (PREC == 3 ? 2 : 
                 __syncthreads();
             }
         }
+        }   // cb_lo < CB
     } else {
     // chunks of this pipeline: grp, grp + KS, ...  (an index past the end addresses k >= K: the A operand
     // reads as zero there, so the surplus iteration of the odd pipeline adds nothing)
@@ -786,7 +799,7 @@ __global__ __launch_bounds__(256 * KS, (BK == 16 && KS == 1) ? (PREC == 3 ? 2 : 
     const bool has_res = p.res != nullptr;
     // first row of this thread.  Patch mode: tile row r is pixel (r / 16, r % 16) of the patch, so the thread's first row is a
     // pixel index and the step from it to row_of(q) is srow(q) pixels (wave-uniform: it goes into the scalar offset as before)
-    const int mb0 = PATCH ? (pt_b * p.Hin + pt_y0 + ((wm * WM) >> 4)) * p.Win + pt_x0 + 4 * (lane >> 5) : m0 + wm * WM + 4 * (lane >> 5);
+    const int mb0 = PATCH ? (pt_b * p.Hin + pt_y0 + (wm * WM) / kPW) * p.Win + pt_x0 + 4 * (lane >> 5) : m0 + wm * WM + 4 * (lane >> 5);
     const int lim = PATCH ? 0x7fffffff : Mrows - mb0;     // relative rows r < lim exist (a patch is always whole)
     constexpr int EB = EPI == OFX_EPI_GRU_Q ? 4 : 8;
     // Control flow is kept out of the element loops: the optional reads are decided once per batch of EB
@@ -882,7 +895,9 @@ __global__ __launch_bounds__(256 * KS, (BK == 16 && KS == 1) ? (PREC == 3 ? 2 : 
                     auto row_of = [&](int q) { const int e = e0 + q; return i * 32 + (e & 3) + 8 * (e >> 2); };
                     auto srow = [&](int q) {
                         const int e = e0 + q;
-                        return PATCH ? (2 * i + (e >> 3)) * p.Win + (e & 3) + 8 * ((e >> 2) & 1) : row_of(q);
+                        return !PATCH ? row_of(q)
+                               : kPW == 16 ? (2 * i + (e >> 3)) * p.Win + (e & 3) + 8 * ((e >> 2) & 1)
+                                           : (4 * i + (e >> 2)) * p.Win + (e & 3);
                     };
                     auto mask_of = [&](int r) { return FULL ? 0 : (r < lim ? 0 : kOOB); };
                     if (has_add) {
@@ -974,7 +989,7 @@ int launch_tile_uk(const ConvK& k, int epi, bool norm, int nz, hipStream_t s) {
 
 template <int BM, int BN, int WM, int WN, int BK, int PREC = 0, int KS = 1, bool SK = false>
 int launch_tile(const ConvK& k, int epi, bool norm, int nz, hipStream_t s) {
-    if constexpr (PREC == 0 && BM == 128 && BK == 16 && KS == 1 && !SK && (BN == 64 || BN == 96 || BN == 128 || BN == 192)) {
+    if constexpr (PREC == 0 && KS == 1 && ((BM == 128 && BK == 16 && !SK && (BN == 64 || BN == 96 || BN == 128 || BN == 192)) || (BM == 64 && BN == 64 && BK == 32))) {
         if (k.patch && epi != OFX_EPI_FLOW && epi != kEpiVolPool) return launch_tile_uk<BM, BN, WM, WN, BK, PREC, KS, SK, 2>(k, epi, norm, nz, s);
     }
     if constexpr (PREC == 0 && BN != 192) {   // the 128x192 tile measured 0.8 % slower with scalar chunk coordinates
@@ -1186,11 +1201,12 @@ extern "C" int ofx_conv2d_alpha(const ofx_conv_desc* d, float alpha, void* strea
     static const bool no_patch = getenv("OFX_CONV_NO_PATCH") != nullptr;
     const bool shape_ok = (d->KH == 3 && d->KW == 3) || (d->KH == 1 && d->KW == 5) || (d->KH == 5 && d->KW == 1);
     k.KH = d->KH;
+    const bool big = bm == 128 && bk == 16, small = bm == 64 && bn == 64 && bk == 32;      // 8x16 patches / 8x8 patches (small grids, split-K)
+    const int pw = big ? 16 : 8;
     k.patch = (!no_patch && d->precision == OFX_PREC_FP32 && shape_ok && d->stride == 1 && d->padH == d->KH / 2 && d->padW == d->KW / 2 &&
-               d->Hin == d->Hout && d->Win == d->Wout && d->Hin % 8 == 0 && d->Win % 16 == 0 && k.cin % 16 == 0 &&
-               (d->c1 == 0 || d->c0 % 16 == 0) && (!d->nmean || d->c1 == 0) && nz == 1 && bm == 128 && bk == 16 && M % 128 == 0)
+               d->Hin == d->Hout && d->Win == d->Wout && d->Hin % 8 == 0 && d->Win % pw == 0 && k.cin % bk == 0 &&
+               (d->c1 == 0 || d->c0 % bk == 0) && (!d->nmean || d->c1 == 0) && nz == 1 && (big || small))
                   ? 1 : 0;
-    if (k.patch) k.ksplit = 1;
     if (d->precision != OFX_PREC_FP32) {
         // split-bf16 matrix-core path (opt-in): three tiles; every other choice is mapped onto them (the ragged
         // N of a 96- or 2-channel layer is zero-filled by the descriptors)

@@ -164,12 +164,15 @@ def test_conv2d_bf16x6_mode_is_fp32_accurate(cuda, case):
 @pytest.mark.parametrize("case", [  # B, H, W, c0, c1, cout, kh, kw, tile
     (2, 16, 32, 64, 0, 64, 3, 3, 16128064), (1, 24, 48, 256, 0, 192, 3, 3, 16128192), (2, 8, 16, 128, 256, 256, 1, 5, 16128128),
     (1, 40, 16, 128, 128, 128, 5, 1, 16128128), (3, 8, 32, 96, 0, 96, 3, 3, 16128096), (1, 64, 96, 128, 0, 256, 3, 3, 16128128),
-    (1, 16, 16, 16, 0, 70, 3, 3, 16128128)])
+    (1, 16, 16, 16, 0, 70, 3, 3, 16128128),
+    # the 64x64 small-grid tile: 8x8 patches, 32-channel slabs
+    (2, 16, 24, 64, 0, 64, 3, 3, 32064064), (1, 8, 40, 128, 256, 256, 1, 5, 32064064), (1, 24, 8, 128, 128, 128, 5, 1, 32064064),
+    (1, 32, 32, 96, 0, 100, 3, 3, 32064064)])
 def test_conv2d_halo_patch_kernel(cuda, case):
     """The halo-patch instantiation (stride-1 3x3 / 1x5 / 5x1 on maps made of whole 8x16 patches; forced here through the
     128-row tile override, the executor reaches it by itself at batch size) against F.conv2d: borders, every tile width, one
     and two input segments, addend / residual / scale epilogue, a ragged N; and against the general kernel (OFX_CONV_NO_PATCH
-    is read once per process, so the comparison is with the 64x64 tile, which never takes the patch path)."""
+    is read once per process, so the comparison is with the 64x64 BK = 16 tile, which never takes the patch path)."""
     ops = _ops()
     B, H, W, c0, c1, co, kh, kw, tile = case
     g = torch.Generator().manual_seed(sum(case))
@@ -186,9 +189,16 @@ def test_conv2d_halo_patch_kernel(cuda, case):
     kwargs = dict(shift=sh.cuda(), scale=sc.cuda(), act="relu", x2=None if xb is None else nhwc(xb), res=nhwc(res))
     out = ops.conv2d_nhwc(nhwc(xa), ops.pack_conv_weight(w).cuda(), kh, kw, co, tile=tile, **kwargs)
     assert (nchw(out) - ref).abs().max().item() < 2e-5
-    gen = ops.conv2d_nhwc(nhwc(xa), ops.pack_conv_weight(w).cuda(), kh, kw, co, tile=32064064, **kwargs)
+    gen = ops.conv2d_nhwc(nhwc(xa), ops.pack_conv_weight(w).cuda(), kh, kw, co, tile=16064064, **kwargs)
     assert (nchw(gen) - ref).abs().max().item() < 2e-5
     assert not torch.equal(out, gen) or ci <= 16            # another summation order: the patch path really ran
+    if tile == 32064064:
+        # split-K over channel slabs (the executor's small-grid schedule): automatic tile choice + a split-K workspace
+        ws = torch.zeros((64 << 20,), dtype=torch.uint8, device="cuda")
+        sk = ops.conv2d_nhwc(nhwc(xa), ops.pack_conv_weight(w).cuda(), kh, kw, co, splitk_ws=ws, **kwargs)
+        assert (nchw(sk) - ref).abs().max().item() < 2e-5
+        sk2 = ops.conv2d_nhwc(nhwc(xa), ops.pack_conv_weight(w).cuda(), kh, kw, co, splitk_ws=ws, **kwargs)
+        assert torch.equal(sk, sk2)                          # deterministic reduction order
 
 
 def test_conv2d_halo_patch_with_fused_instance_norm(cuda):
