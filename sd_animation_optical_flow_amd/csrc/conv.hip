@@ -237,8 +237,8 @@ __global__ __launch_bounds__(256 * KS, (BK == 16 && KS == 1) ? (PREC == 3 ? 2 : 
     // patch origin of this tile (MODE 2): mt enumerates the 8x16 patches of the batch in raster order
     int pt_b = 0, pt_y0 = 0, pt_x0 = 0;
     if constexpr (PATCH) {
-        const int tpr = p.Win / kPW;
-        const int tpi = (p.Hin >> 3) * tpr;
+        const int tpr = (p.Win + kPW - 1) / kPW;           // patches per image row / per image: the last ones may hang over the map
+        const int tpi = ((p.Hin + 7) >> 3) * tpr;
         pt_b = mt / tpi;
         const int trem = mt - pt_b * tpi;
         const int ty = trem / tpr;
@@ -800,7 +800,10 @@ __global__ __launch_bounds__(256 * KS, (BK == 16 && KS == 1) ? (PREC == 3 ? 2 : 
     // first row of this thread.  Patch mode: tile row r is pixel (r / 16, r % 16) of the patch, so the thread's first row is a
     // pixel index and the step from it to row_of(q) is srow(q) pixels (wave-uniform: it goes into the scalar offset as before)
     const int mb0 = PATCH ? (pt_b * p.Hin + pt_y0 + (wm * WM) / kPW) * p.Win + pt_x0 + 4 * (lane >> 5) : m0 + wm * WM + 4 * (lane >> 5);
-    const int lim = PATCH ? 0x7fffffff : Mrows - mb0;     // relative rows r < lim exist (a patch is always whole)
+    const int lim = PATCH ? 0x7fffffff : Mrows - mb0;     // relative rows r < lim exist
+    // overhanging patches: rows / columns of the map left below / right of this thread's first pixel
+    const int pt_ylim = p.Hin - pt_y0 - (wm * WM) / kPW;
+    const int pt_xlim = p.Win - pt_x0 - 4 * (lane >> 5);
     constexpr int EB = EPI == OFX_EPI_GRU_Q ? 4 : 8;
     // Control flow is kept out of the element loops: the optional reads are decided once per batch of EB
     // elements, ReLU / the residual ReLU are a max against 0 or -FLT_MAX, the transcendental activations of the
@@ -899,7 +902,16 @@ __global__ __launch_bounds__(256 * KS, (BK == 16 && KS == 1) ? (PREC == 3 ? 2 : 
                                : kPW == 16 ? (2 * i + (e >> 3)) * p.Win + (e & 3) + 8 * ((e >> 2) & 1)
                                            : (4 * i + (e >> 2)) * p.Win + (e & 3);
                     };
-                    auto mask_of = [&](int r) { return FULL ? 0 : (r < lim ? 0 : kOOB); };
+                    // rows of the tile that do not exist: past M (general), or pixels of an overhanging patch outside the map
+                    auto mask_of = [&](int r) {
+                        if constexpr (FULL) return 0;
+                        if constexpr (!PATCH) return r < lim ? 0 : kOOB;
+                        const int e = r & 31;                 // r = i * 32 + (e & 3) + 8 * (e >> 2), the lane's 4 * h sits in pt_xl
+                        const int ii = r >> 5;
+                        const int py = kPW == 16 ? 2 * ii + (e >> 4) : 4 * ii + (e >> 3);
+                        const int px = kPW == 16 ? (e & 3) + (e & 8) : (e & 3);
+                        return (py < pt_ylim && px < pt_xlim) ? 0 : kOOB;
+                    };
                     if (has_add) {
 #pragma unroll
                         for (int q = 0; q < EB; ++q) ad[q] = ldf(rs_add, vo_add | mask_of(row_of(q)), srow(q) * p.ldadd * 4);
@@ -949,7 +961,7 @@ __global__ __launch_bounds__(256 * KS, (BK == 16 && KS == 1) ? (PREC == 3 ? 2 : 
             }
         }
     };
-    if (PATCH || m0 + BM <= Mrows) epilogue(std::true_type{});
+    if (PATCH ? (pt_y0 + 8 <= p.Hin && pt_x0 + kPW <= p.Win) : (m0 + BM <= Mrows)) epilogue(std::true_type{});
     else epilogue(std::false_type{});
 }
 
@@ -1203,10 +1215,15 @@ extern "C" int ofx_conv2d_alpha(const ofx_conv_desc* d, float alpha, void* strea
     k.KH = d->KH;
     const bool big = bm == 128 && bk == 16, small = bm == 64 && bn == 64 && bk == 32;      // 8x16 patches / 8x8 patches (small grids, split-K)
     const int pw = big ? 16 : 8;
+    // the 128-row tiles also take maps that are not whole patches (the last patch of a row / column hangs over: its outside
+    // pixels stage zeros and are masked in the epilogue); the small tile, whose grid feeds the split-K choice above, does not
+    const bool whole = d->Hin % 8 == 0 && d->Win % pw == 0;
     k.patch = (!no_patch && d->precision == OFX_PREC_FP32 && shape_ok && d->stride == 1 && d->padH == d->KH / 2 && d->padW == d->KW / 2 &&
-               d->Hin == d->Hout && d->Win == d->Wout && d->Hin % 8 == 0 && d->Win % pw == 0 && k.cin % bk == 0 &&
-               (d->c1 == 0 || d->c0 % bk == 0) && (!d->nmean || d->c1 == 0) && nz == 1 && (big || small))
+               d->Hin == d->Hout && d->Win == d->Wout && (whole || big) && k.cin % bk == 0 &&
+               (d->c1 == 0 || d->c0 % bk == 0) && (!d->nmean || d->c1 == 0) && nz == 1 && (big || small) &&
+               (bn == 64 || bn == 96 || bn == 128 || bn == 192) && d->epi != OFX_EPI_FLOW)
                   ? 1 : 0;
+    if (k.patch && !whole) k.mtiles = d->B * ((d->Hin + 7) / 8) * ((d->Win + 15) / 16);
     if (d->precision != OFX_PREC_FP32) {
         // split-bf16 matrix-core path (opt-in): three tiles; every other choice is mapped onto them (the ragged
         // N of a 96- or 2-channel layer is zero-filled by the descriptors)

@@ -275,6 +275,27 @@ def test_bench_workload_c3_b64_20iters_512x768(engine, raft_sd):
         assert np.array_equal(mask[b].cpu().numpy(), ref_m)
 
 
+def test_large_batch_on_a_map_that_is_not_whole_patches(engine, raft_sd):
+    """64 frames of 264x392: every resolution of the network (132x196, 66x98, 33x49) leaves the last 8x16 patch of each row and
+    column hanging over the map, and the batch is large enough for the 128-row halo-patch tiles.  Two frames against the CPU
+    oracle, every frame against its own single-pair run (which takes the small-grid kernels)."""
+    import bench
+    B, H, W, iters = 64, 264, 392, 6
+    frames, key, _, _ = bench.make_clip(B, H, W, torch.device("cuda"))
+    flow = engine.forward(frames, key, iters=iters)
+    assert tuple(flow.shape) == (B, H, W, 2) and torch.isfinite(flow).all()
+    kf = key.cpu().permute(2, 0, 1)[None].float()
+    for b in (0, 63):
+        _, up = RO.raft_forward(raft_sd, frames[b].cpu().permute(2, 0, 1)[None].float(), kf, iters=iters)
+        e = _epe(flow[b].cpu(), up[0].permute(1, 2, 0))
+        assert e < 1e-3, (b, e)
+    worst = 0.0
+    for b in range(0, B, 7):
+        single = engine.forward(frames[b:b + 1], key, iters=iters)
+        worst = max(worst, (flow[b:b + 1] - single).abs().max().item())
+    assert worst < 1e-3, worst
+
+
 def test_saturated_gates_stay_inside_the_bar(cuda, raft_sd):
     """The GRU epilogues evaluate sigmoid / tanh with v_exp_f32 / v_rcp_f32 (ofx_internal.h) instead of libm.  A trained
     checkpoint drives the gates into saturation far more than seeded weights do: scale the update block's gate and
