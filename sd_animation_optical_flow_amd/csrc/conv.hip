@@ -127,7 +127,7 @@ __global__ __launch_bounds__(256 * KS, (BK == 16 && KS == 1) ? (PREC == 3 ? 2 : 
     static_assert((BM / WM) * (BN / WN) == 4, "4 waves per workgroup");
     static_assert(KS == 1 || KS == 2, "one or two pipelines");
     static_assert(KS == 1 || 2 * STAGE * KS >= 256 * TM * TN * 16, "accumulator exchange must fit the staging buffers");
-    __shared__ __attribute__((aligned(16))) float smem_all[PATCH ? (kPatchRows + 2 * BN_ST) * LDK : 2 * STAGE * KS];
+    __shared__ __attribute__((aligned(16))) float smem_all[!PATCH ? 2 * STAGE * KS : PREC == 0 ? (kPatchRows + 2 * BN_ST) * LDK : (kPatchRows + 2 * BN_ST) * 2 * (ROWB / 4)];
     const int grp = KS == 1 ? 0 : (int)(threadIdx.x >> 8);      // pipeline this thread belongs to
     float* const smem = smem_all + grp * (2 * STAGE);
 
@@ -247,8 +247,8 @@ __global__ __launch_bounds__(256 * KS, (BK == 16 && KS == 1) ? (PREC == 3 ? 2 : 
     }
 
     if constexpr (PATCH) {
-        static_assert(!PATCH || (PREC == 0 && KS == 1 && ((BM == 128 && (WM == 64 || WM == 32) && BK == 16 && !SK) || (BM == 64 && WM == 32 && BK == 32))),
-                      "patch mode: 128-row tiles with 16-channel slabs, or the 64x64 small-grid tile with 32-channel slabs (split-K allowed)");
+        static_assert(!PATCH || (PREC <= 2 && KS == 1 && ((BM == 128 && (WM == 64 || WM == 32) && BK == 16 && !SK) || (PREC == 0 && BM == 64 && WM == 32 && BK == 32))),
+                      "patch mode: 128-row tiles with 16-channel slabs (fp32 or bf16x3), or the fp32 64x64 small-grid tile with 32-channel slabs (split-K allowed)");
         static_assert(!PATCH || (EPI != OFX_EPI_FLOW && EPI != kEpiVolPool), "patch mode: plain / GRU epilogues");
         typedef int v4i __attribute__((ext_vector_type(4)));
         const int PWH = kPW + p.KW - 1;                      // halo patch width in pixels
@@ -258,9 +258,14 @@ __global__ __launch_bounds__(256 * KS, (BK == 16 && KS == 1) ? (PREC == 3 ? 2 : 
         const int cb_per = SK ? (CBall + p.ksplit - 1) / p.ksplit : CBall;
         const int cb_lo = SK ? min(split * cb_per, CBall) : 0;
         const int CB = SK ? min(cb_lo + cb_per, CBall) : CBall;   // exclusive upper bound
-        float* const Apatch = smem_all;                      // [kPatchRows][LDK]
-        float* const Bst = smem_all + kPatchRows * LDK;      // two stages of [BN_ST][LDK]
-        constexpr int BSTAGE = BN_ST * LDK;
+        // fp32: [kPatchRows][LDK] floats, then two weight stages of [BN_ST][LDK].  bf16x3: the same rows as (hi, lo) bf16 pieces of
+        // ROWB bytes each -- patch hi | patch lo | two stages of (weights hi | weights lo)
+        constexpr int AROWF = PREC == 0 ? LDK : ROWB / 4;    // floats per staged row (of one piece)
+        constexpr int APIECE = kPatchRows * AROWF;           // floats per A piece
+        constexpr int BPIECE = BN_ST * AROWF;
+        float* const Apatch = smem_all;
+        float* const Bst = smem_all + (PREC == 0 ? 1 : 2) * APIECE;
+        constexpr int BSTAGE = (PREC == 0 ? 1 : 2) * BPIECE;
         // the (row, float4 slot) pairs this thread stages per slab; rows permuted like r0 (conflict-free ds_write_b128)
         constexpr int NSLOT = (kPatchRows * QPR + 255) / 256;
         constexpr int SROWS = 256 / QPR;                     // rows between a thread's consecutive slots
@@ -270,14 +275,15 @@ __global__ __launch_bounds__(256 * KS, (BK == 16 && KS == 1) ? (PREC == 3 ? 2 : 
 #pragma unroll
         for (int q = 0; q < NSLOT; ++q) {
             const int j = tid / QPR + SROWS * q;
-            const int row = (j % kG) * kS + (j / kG) % kS + (j / (kG * kS)) * (kG * kS);
+            // fp32: 16-byte writes, rows 4 apart inside a group of 16; bf16 pieces: 8-byte writes, same-parity rows (see r0)
+            const int row = PREC == 0 ? (j % kG) * kS + (j / kG) % kS + (j / (kG * kS)) * (kG * kS) : 16 * (j / 16) + 2 * (j % 8) + ((j / 8) & 1);
             const int hy = row / PWH, hx = row - hy * PWH;
             const int gy = pt_y0 - p.padH + hy, gx = pt_x0 - p.padW + hx;
             const bool ok = j < kPatchRows && row < (8 + p.KH - 1) * PWH && (unsigned)gy < (unsigned)p.Hin && (unsigned)gx < (unsigned)p.Win;
             const int pix = (pt_b * p.Hin + gy) * p.Win + gx;
             avo0[q] = ok ? pix * (p.ld0 * 4) + kq * 16 : kOOB;
             avo1[q] = ok ? pix * (p.ld1 * 4) + kq * 16 : kOOB;
-            if (q == 0) alds0 = row * LDK + kq * 4;
+            if (q == 0) alds0 = PREC == 0 ? row * LDK + kq * 4 : row * ROWB + kq * 8;   // floats / bytes
             aval |= (ok ? 1u : 0u) << q;
         }
         const int frow = lane & 31, fk = (lane >> 5) * 4;
@@ -285,11 +291,22 @@ __global__ __launch_bounds__(256 * KS, (BK == 16 && KS == 1) ? (PREC == 3 ? 2 : 
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
             const int r = wm * WM + i * 32 + frow;
-            afr[i] = ((r / kPW) * PWH + (r % kPW)) * LDK + fk;
+            afr[i] = PREC == 0 ? ((r / kPW) * PWH + (r % kPW)) * LDK + fk : ((r / kPW) * PWH + (r % kPW)) * ROWB + (lane >> 5) * 16;
         }
 #pragma unroll
-        for (int j = 0; j < TN; ++j) bfr[j] = (wn * WN + j * 32 + frow) * LDK + fk;
+        for (int j = 0; j < TN; ++j) bfr[j] = PREC == 0 ? (wn * WN + j * 32 + frow) * LDK + fk : (wn * WN + j * 32 + frow) * ROWB + (lane >> 5) * 16;
 
+        // fp32 -> (hi, lo) bf16 pair, round-to-nearest-even both times (as in the general path's commit)
+        auto split_store = [&](char* hi_row, char* lo_row, float4 v) __attribute__((always_inline)) {
+            typedef float f4 __attribute__((ext_vector_type(4)));
+            typedef __bf16 b4 __attribute__((ext_vector_type(4)));
+            const f4 x = {v.x, v.y, v.z, v.w};
+            const b4 hh = __builtin_convertvector(x, b4);
+            const f4 rr = x - __builtin_convertvector(hh, f4);
+            const b4 ll = __builtin_convertvector(rr, b4);
+            *reinterpret_cast<b4*>(hi_row) = hh;
+            *reinterpret_cast<b4*>(lo_row) = ll;
+        };
         float4 pa[NSLOT];
         float4 pmu = make_float4(0.f, 0.f, 0.f, 0.f), prs = pmu;
         float4 rb0 = make_float4(0.f, 0.f, 0.f, 0.f), rb1 = rb0, rb2 = rb0, rb3 = rb0;
@@ -320,7 +337,12 @@ __global__ __launch_bounds__(256 * KS, (BK == 16 && KS == 1) ? (PREC == 3 ? 2 : 
                     v.w = fmaxf((v.w - pmu.w) * prs.w, 0.f);
                     if (!((aval >> q) & 1u)) v = make_float4(0.f, 0.f, 0.f, 0.f);
                 }
-                *reinterpret_cast<float4*>(&Apatch[alds0 + q * SROWS * LDK]) = v;
+                if constexpr (PREC == 0) {
+                    *reinterpret_cast<float4*>(&Apatch[alds0 + q * SROWS * LDK]) = v;
+                } else {
+                    char* hi = reinterpret_cast<char*>(Apatch) + alds0 + q * SROWS * ROWB;
+                    split_store(hi, hi + APIECE * 4, v);
+                }
             }
         };
         // weight chunks are issued two ahead of the one being multiplied: (itap, icb) is the next one to issue
@@ -336,13 +358,58 @@ __global__ __launch_bounds__(256 * KS, (BK == 16 && KS == 1) ? (PREC == 3 ? 2 : 
             }
         };
         auto b_commit = [&](float* Bs) __attribute__((always_inline)) {
+            if constexpr (PREC == 0) {
 #define OFX_B_COMMIT(i) \
     if constexpr (B_PER > i) *reinterpret_cast<float4*>(&Bs[(r0 + RPG * i) * LDK + kq * 4]) = rb##i;
-            OFX_B_COMMIT(0) OFX_B_COMMIT(1) OFX_B_COMMIT(2) OFX_B_COMMIT(3)
+                OFX_B_COMMIT(0) OFX_B_COMMIT(1) OFX_B_COMMIT(2) OFX_B_COMMIT(3)
 #undef OFX_B_COMMIT
+            } else {
+                char* b_hi = reinterpret_cast<char*>(Bs);
+                char* b_lo = b_hi + BPIECE * 4;
+                // PREC = 2: the weight matrix arrives pre-split ([hi x4 | lo x4] per 16 bytes)
+#define OFX_B_COMMIT(i) \
+    if constexpr (B_PER > i) { \
+        const int o = (r0 + RPG * i) * ROWB + kq * 8; \
+        if constexpr (PREC == 2) { \
+            *reinterpret_cast<float2*>(b_hi + o) = make_float2(rb##i.x, rb##i.y); \
+            *reinterpret_cast<float2*>(b_lo + o) = make_float2(rb##i.z, rb##i.w); \
+        } else { \
+            split_store(b_hi + o, b_lo + o, rb##i); \
+        } \
+    }
+                OFX_B_COMMIT(0) OFX_B_COMMIT(1) OFX_B_COMMIT(2) OFX_B_COMMIT(3)
+#undef OFX_B_COMMIT
+            }
         };
 
         auto step = [&](int c, int ky, int kx) __attribute__((always_inline)) {
+            if constexpr (PREC != 0) {
+                // bf16x3 on the patch: acc += a_hi*b_hi + a_hi*b_lo + a_lo*b_hi, one 16-wide k-step per tap
+                typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+                const char* a_hi = reinterpret_cast<const char*>(Apatch) + (ky * PWH + kx) * ROWB;
+                const char* a_lo = a_hi + APIECE * 4;
+                const char* b_hi = reinterpret_cast<const char*>(Bst + (c & 1) * BSTAGE);
+                const char* b_lo = b_hi + BPIECE * 4;
+                bf16x8 ah[TM], al[TM], bh[TN], bl[TN];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    ah[i] = *reinterpret_cast<const bf16x8*>(a_hi + afr[i]);
+                    al[i] = *reinterpret_cast<const bf16x8*>(a_lo + afr[i]);
+                }
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    bh[j] = *reinterpret_cast<const bf16x8*>(b_hi + bfr[j]);
+                    bl[j] = *reinterpret_cast<const bf16x8*>(b_lo + bfr[j]);
+                }
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                    }
+            } else {
             const float* As = Apatch + (ky * PWH + kx) * LDK;
             const float* Bs = Bst + (c & 1) * BSTAGE;
 #pragma unroll
@@ -361,6 +428,7 @@ __global__ __launch_bounds__(256 * KS, (BK == 16 && KS == 1) ? (PREC == 3 ? 2 : 
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].z, fb[j].z, acc[i][j], 0, 0, 0);
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].w, fb[j].w, acc[i][j], 0, 0, 0);
                     }
+            }
             }
             b_commit(Bst + ((c + 1) & 1) * BSTAGE);          // chunk c + 1 has had this MFMA block to land
             __syncthreads();
@@ -1001,7 +1069,8 @@ int launch_tile_uk(const ConvK& k, int epi, bool norm, int nz, hipStream_t s) {
 
 template <int BM, int BN, int WM, int WN, int BK, int PREC = 0, int KS = 1, bool SK = false>
 int launch_tile(const ConvK& k, int epi, bool norm, int nz, hipStream_t s) {
-    if constexpr (PREC == 0 && KS == 1 && ((BM == 128 && BK == 16 && !SK && (BN == 64 || BN == 96 || BN == 128 || BN == 192)) || (BM == 64 && BN == 64 && BK == 32))) {
+    if constexpr (KS == 1 && ((PREC == 0 && BM == 128 && BK == 16 && !SK && (BN == 64 || BN == 96 || BN == 128 || BN == 192)) || (PREC == 0 && BM == 64 && BN == 64 && BK == 32) ||
+                              ((PREC == 1 || PREC == 2) && BM == 128 && BK == 16 && !SK && (BN == 64 || BN == 128)))) {
         if (k.patch && epi != OFX_EPI_FLOW && epi != kEpiVolPool) return launch_tile_uk<BM, BN, WM, WN, BK, PREC, KS, SK, 2>(k, epi, norm, nz, s);
     }
     if constexpr (PREC == 0 && BN != 192) {   // the 128x192 tile measured 0.8 % slower with scalar chunk coordinates
@@ -1238,6 +1307,14 @@ extern "C" int ofx_conv2d_alpha(const ofx_conv_desc* d, float alpha, void* strea
             return OFX_EINVAL;
         }
         const bool wsplit = d->precision == OFX_PREC_BF16X3_W;
+        // bf16x3 on the halo patch (128-row tiles, BK = 16): the fp32 -> (hi, lo) conversion of the A side then runs once per
+        // 16-channel slab instead of once per tap
+        const bool whole16 = d->Hin % 8 == 0 && d->Win % 16 == 0;
+        k.patch = (!no_patch && shape_ok && d->stride == 1 && d->padH == d->KH / 2 && d->padW == d->KW / 2 && d->Hin == d->Hout &&
+                   d->Win == d->Wout && k.cin % 16 == 0 && (d->c1 == 0 || d->c0 % 16 == 0) && (!d->nmean || d->c1 == 0) && nz == 1 &&
+                   bm == 128 && tile_bk != 32 && d->epi != OFX_EPI_FLOW)
+                      ? 1 : 0;
+        k.mtiles = k.patch && !whole16 ? d->B * ((d->Hin + 7) / 8) * ((d->Win + 15) / 16) : (int)((M + bm - 1) / bm);
         if (bm == 128 && bn == 128 && tile_bk == 32 && !wsplit) return launch_tile<128, 128, 64, 64, 32, 1>(k, d->epi, norm, nz, s);
         if (bm == 128 && bn == 128) return wsplit ? launch_tile<128, 128, 64, 64, 16, 2>(k, d->epi, norm, nz, s) : launch_tile<128, 128, 64, 64, 16, 1>(k, d->epi, norm, nz, s);
         if (bm == 128 && bn == 64) return wsplit ? launch_tile<128, 64, 64, 32, 16, 2>(k, d->epi, norm, nz, s) : launch_tile<128, 64, 64, 32, 16, 1>(k, d->epi, norm, nz, s);

@@ -215,6 +215,32 @@ def test_conv2d_halo_patch_with_fused_instance_norm(cuda):
     assert (nchw(out) - ref).abs().max().item() < 5e-5
 
 
+@pytest.mark.parametrize("case", [(2, 16, 32, 64, 0, 64, 3, 3, 16128064), (1, 24, 48, 128, 128, 256, 1, 5, 16128128), (1, 13, 22, 128, 0, 128, 3, 3, 16128128),
+                                  (1, 40, 16, 96, 0, 100, 5, 1, 16128128)])
+def test_conv2d_halo_patch_kernel_bf16x3(cuda, case):
+    """The split-bf16 arithmetic on the halo patch (conversion once per slab): same error bar as the general bf16x3 kernel, and
+    the pre-split weight format is bit-identical to splitting on the fly."""
+    ops = _ops()
+    B, H, W, c0, c1, co, kh, kw, tile = case
+    g = torch.Generator().manual_seed(sum(case) + 5)
+    xa = torch.randn((B, c0, H, W), generator=g)
+    xb = torch.randn((B, c1, H, W), generator=g) if c1 else None
+    ci = c0 + c1
+    w = torch.randn((co, ci, kh, kw), generator=g) / np.sqrt(ci * kh * kw)
+    b = torch.randn((co,), generator=g)
+    xin = xa if xb is None else torch.cat([xa, xb], 1)
+    ref = torch.relu(F.conv2d(xin.double(), w.double(), b.double(), padding=(kh // 2, kw // 2))).float()
+    wp = ops.pack_conv_weight(w).cuda()
+    kwargs = dict(shift=b.cuda(), act="relu", x2=None if xb is None else nhwc(xb))
+    out = ops.conv2d_nhwc(nhwc(xa), wp, kh, kw, co, tile=tile, precision="bf16x3", **kwargs)
+    e = (nchw(out) - ref).abs().max().item()
+    assert 0 < e < 2e-4, e
+    outw = ops.conv2d_nhwc(nhwc(xa), ops.split_conv_weight(wp.cpu()).cuda(), kh, kw, co, tile=tile, precision="bf16x3_w", **kwargs)
+    assert torch.equal(outw, out)
+    gen = ops.conv2d_nhwc(nhwc(xa), wp, kh, kw, co, tile=16064064, precision="bf16x3", **kwargs)      # 64-row tile: general path
+    assert (gen - out).abs().max().item() < 2e-4 and not torch.equal(gen, out)
+
+
 def test_conv2d_two_segments_residual_and_scale(cuda):
     ops = _ops()
     g = torch.Generator().manual_seed(3)
