@@ -127,7 +127,7 @@ __global__ __launch_bounds__(256 * KS, (BK == 16 && KS == 1) ? (PREC == 3 ? 2 : 
     static_assert((BM / WM) * (BN / WN) == 4, "4 waves per workgroup");
     static_assert(KS == 1 || KS == 2, "one or two pipelines");
     static_assert(KS == 1 || 2 * STAGE * KS >= 256 * TM * TN * 16, "accumulator exchange must fit the staging buffers");
-    __shared__ __attribute__((aligned(16))) float smem_all[!PATCH ? 2 * STAGE * KS : PREC == 0 ? (kPatchRows + 2 * BN_ST) * LDK : (kPatchRows + 2 * BN_ST) * 2 * (ROWB / 4)];
+    __shared__ __attribute__((aligned(16))) float smem_all[!PATCH ? 2 * STAGE * KS : PREC == 0 ? (kPatchRows + 2 * BN_ST) * LDK : (kPatchRows + 2 * BN_ST) * (PREC == 3 ? 3 : 2) * (ROWB / 4)];
     const int grp = KS == 1 ? 0 : (int)(threadIdx.x >> 8);      // pipeline this thread belongs to
     float* const smem = smem_all + grp * (2 * STAGE);
 
@@ -247,7 +247,7 @@ __global__ __launch_bounds__(256 * KS, (BK == 16 && KS == 1) ? (PREC == 3 ? 2 : 
     }
 
     if constexpr (PATCH) {
-        static_assert(!PATCH || (PREC <= 2 && KS == 1 && ((BM == 128 && (WM == 64 || WM == 32) && BK == 16 && !SK) || (PREC == 0 && BM == 64 && WM == 32 && BK == 32))),
+        static_assert(!PATCH || (PREC <= 3 && KS == 1 && ((BM == 128 && (WM == 64 || WM == 32) && BK == 16 && !SK) || (PREC == 0 && BM == 64 && WM == 32 && BK == 32))),
                       "patch mode: 128-row tiles with 16-channel slabs (fp32 or bf16x3), or the fp32 64x64 small-grid tile with 32-channel slabs (split-K allowed)");
         static_assert(!PATCH || (EPI != OFX_EPI_FLOW && EPI != kEpiVolPool), "patch mode: plain / GRU epilogues");
         typedef int v4i __attribute__((ext_vector_type(4)));
@@ -264,8 +264,9 @@ __global__ __launch_bounds__(256 * KS, (BK == 16 && KS == 1) ? (PREC == 3 ? 2 : 
         constexpr int APIECE = kPatchRows * AROWF;           // floats per A piece
         constexpr int BPIECE = BN_ST * AROWF;
         float* const Apatch = smem_all;
-        float* const Bst = smem_all + (PREC == 0 ? 1 : 2) * APIECE;
-        constexpr int BSTAGE = (PREC == 0 ? 1 : 2) * BPIECE;
+        constexpr int NPIECE = PREC == 0 ? 1 : PREC == 3 ? 3 : 2;
+        float* const Bst = smem_all + NPIECE * APIECE;
+        constexpr int BSTAGE = NPIECE * BPIECE;
         // the (row, float4 slot) pairs this thread stages per slab; rows permuted like r0 (conflict-free ds_write_b128)
         constexpr int NSLOT = (kPatchRows * QPR + 255) / 256;
         constexpr int SROWS = 256 / QPR;                     // rows between a thread's consecutive slots
@@ -307,6 +308,20 @@ __global__ __launch_bounds__(256 * KS, (BK == 16 && KS == 1) ? (PREC == 3 ? 2 : 
             *reinterpret_cast<b4*>(hi_row) = hh;
             *reinterpret_cast<b4*>(lo_row) = ll;
         };
+        // fp32 -> (hi, mid, lo) bf16 triple (bf16x6)
+        auto split_store3 = [&](char* hi_row, char* mid_row, char* lo_row, float4 v) __attribute__((always_inline)) {
+            typedef float f4 __attribute__((ext_vector_type(4)));
+            typedef __bf16 b4 __attribute__((ext_vector_type(4)));
+            const f4 x = {v.x, v.y, v.z, v.w};
+            const b4 hh = __builtin_convertvector(x, b4);
+            const f4 r1 = x - __builtin_convertvector(hh, f4);
+            const b4 mm = __builtin_convertvector(r1, b4);
+            const f4 r2 = r1 - __builtin_convertvector(mm, f4);
+            const b4 ll = __builtin_convertvector(r2, b4);
+            *reinterpret_cast<b4*>(hi_row) = hh;
+            *reinterpret_cast<b4*>(mid_row) = mm;
+            *reinterpret_cast<b4*>(lo_row) = ll;
+        };
         float4 pa[NSLOT];
         float4 pmu = make_float4(0.f, 0.f, 0.f, 0.f), prs = pmu;
         float4 rb0 = make_float4(0.f, 0.f, 0.f, 0.f), rb1 = rb0, rb2 = rb0, rb3 = rb0;
@@ -341,7 +356,8 @@ __global__ __launch_bounds__(256 * KS, (BK == 16 && KS == 1) ? (PREC == 3 ? 2 : 
                     *reinterpret_cast<float4*>(&Apatch[alds0 + q * SROWS * LDK]) = v;
                 } else {
                     char* hi = reinterpret_cast<char*>(Apatch) + alds0 + q * SROWS * ROWB;
-                    split_store(hi, hi + APIECE * 4, v);
+                    if constexpr (PREC == 3) split_store3(hi, hi + APIECE * 4, hi + 2 * APIECE * 4, v);
+                    else split_store(hi, hi + APIECE * 4, v);
                 }
             }
         };
@@ -373,6 +389,8 @@ __global__ __launch_bounds__(256 * KS, (BK == 16 && KS == 1) ? (PREC == 3 ? 2 : 
         if constexpr (PREC == 2) { \
             *reinterpret_cast<float2*>(b_hi + o) = make_float2(rb##i.x, rb##i.y); \
             *reinterpret_cast<float2*>(b_lo + o) = make_float2(rb##i.z, rb##i.w); \
+        } else if constexpr (PREC == 3) { \
+            split_store3(b_hi + o, b_lo + o, b_lo + BPIECE * 4 + o, rb##i); \
         } else { \
             split_store(b_hi + o, b_lo + o, rb##i); \
         } \
@@ -383,7 +401,36 @@ __global__ __launch_bounds__(256 * KS, (BK == 16 && KS == 1) ? (PREC == 3 ? 2 : 
         };
 
         auto step = [&](int c, int ky, int kx) __attribute__((always_inline)) {
-            if constexpr (PREC != 0) {
+            if constexpr (PREC == 3) {
+                // bf16x6 on the patch: pieces (hi, mid, lo) in that order; the six products of weight >= 2^-16, smallest first
+                typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+                const char* a0 = reinterpret_cast<const char*>(Apatch) + (ky * PWH + kx) * ROWB;
+                const char* b0 = reinterpret_cast<const char*>(Bst + (c & 1) * BSTAGE);
+                bf16x8 ah[TM], am[TM], al[TM], bh[TN], bm_[TN], bl[TN];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    ah[i] = *reinterpret_cast<const bf16x8*>(a0 + afr[i]);
+                    am[i] = *reinterpret_cast<const bf16x8*>(a0 + APIECE * 4 + afr[i]);
+                    al[i] = *reinterpret_cast<const bf16x8*>(a0 + 2 * APIECE * 4 + afr[i]);
+                }
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    bh[j] = *reinterpret_cast<const bf16x8*>(b0 + bfr[j]);
+                    bm_[j] = *reinterpret_cast<const bf16x8*>(b0 + BPIECE * 4 + bfr[j]);
+                    bl[j] = *reinterpret_cast<const bf16x8*>(b0 + 2 * BPIECE * 4 + bfr[j]);
+                }
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[i], bm_[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[i], bh[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bm_[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                    }
+            } else if constexpr (PREC != 0) {
                 // bf16x3 on the patch: acc += a_hi*b_hi + a_hi*b_lo + a_lo*b_hi, one 16-wide k-step per tap
                 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
                 const char* a_hi = reinterpret_cast<const char*>(Apatch) + (ky * PWH + kx) * ROWB;
@@ -1070,7 +1117,7 @@ int launch_tile_uk(const ConvK& k, int epi, bool norm, int nz, hipStream_t s) {
 template <int BM, int BN, int WM, int WN, int BK, int PREC = 0, int KS = 1, bool SK = false>
 int launch_tile(const ConvK& k, int epi, bool norm, int nz, hipStream_t s) {
     if constexpr (KS == 1 && ((PREC == 0 && BM == 128 && BK == 16 && !SK && (BN == 64 || BN == 96 || BN == 128 || BN == 192)) || (PREC == 0 && BM == 64 && BN == 64 && BK == 32) ||
-                              ((PREC == 1 || PREC == 2) && BM == 128 && BK == 16 && !SK && (BN == 64 || BN == 128)))) {
+                              ((PREC == 1 || PREC == 2 || PREC == 3) && BM == 128 && BK == 16 && !SK && (BN == 64 || BN == 128)))) {
         if (k.patch && epi != OFX_EPI_FLOW && epi != kEpiVolPool) return launch_tile_uk<BM, BN, WM, WN, BK, PREC, KS, SK, 2>(k, epi, norm, nz, s);
     }
     if constexpr (PREC == 0 && BN != 192) {   // the 128x192 tile measured 0.8 % slower with scalar chunk coordinates
@@ -1300,13 +1347,6 @@ extern "C" int ofx_conv2d_alpha(const ofx_conv_desc* d, float alpha, void* strea
         else if (bn != 64) bn = 128;
         k.ntiles = (d->Cout + bn - 1) / bn;
         k.group_m = k.ntiles >= 8 ? 8 : 1;
-        if (d->precision == OFX_PREC_BF16X6) {
-            if (bm == 128 && bn == 128) return launch_tile<128, 128, 64, 64, 16, 3>(k, d->epi, norm, nz, s);
-            if (bm == 128 && bn == 64) return launch_tile<128, 64, 64, 32, 16, 3>(k, d->epi, norm, nz, s);
-            if (bm == 64 && bn == 64) return launch_tile<64, 64, 32, 32, 16, 3>(k, d->epi, norm, nz, s);
-            return OFX_EINVAL;
-        }
-        const bool wsplit = d->precision == OFX_PREC_BF16X3_W;
         // bf16x3 on the halo patch (128-row tiles, BK = 16): the fp32 -> (hi, lo) conversion of the A side then runs once per
         // 16-channel slab instead of once per tap
         const bool whole16 = d->Hin % 8 == 0 && d->Win % 16 == 0;
@@ -1315,6 +1355,13 @@ extern "C" int ofx_conv2d_alpha(const ofx_conv_desc* d, float alpha, void* strea
                    bm == 128 && tile_bk != 32 && d->epi != OFX_EPI_FLOW)
                       ? 1 : 0;
         k.mtiles = k.patch && !whole16 ? d->B * ((d->Hin + 7) / 8) * ((d->Win + 15) / 16) : (int)((M + bm - 1) / bm);
+        if (d->precision == OFX_PREC_BF16X6) {
+            if (bm == 128 && bn == 128) return launch_tile<128, 128, 64, 64, 16, 3>(k, d->epi, norm, nz, s);
+            if (bm == 128 && bn == 64) return launch_tile<128, 64, 64, 32, 16, 3>(k, d->epi, norm, nz, s);
+            if (bm == 64 && bn == 64) return launch_tile<64, 64, 32, 32, 16, 3>(k, d->epi, norm, nz, s);
+            return OFX_EINVAL;
+        }
+        const bool wsplit = d->precision == OFX_PREC_BF16X3_W;
         if (bm == 128 && bn == 128 && tile_bk == 32 && !wsplit) return launch_tile<128, 128, 64, 64, 32, 1>(k, d->epi, norm, nz, s);
         if (bm == 128 && bn == 128) return wsplit ? launch_tile<128, 128, 64, 64, 16, 2>(k, d->epi, norm, nz, s) : launch_tile<128, 128, 64, 64, 16, 1>(k, d->epi, norm, nz, s);
         if (bm == 128 && bn == 64) return wsplit ? launch_tile<128, 64, 64, 32, 16, 2>(k, d->epi, norm, nz, s) : launch_tile<128, 64, 64, 32, 16, 1>(k, d->epi, norm, nz, s);

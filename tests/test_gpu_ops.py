@@ -241,6 +241,30 @@ def test_conv2d_halo_patch_kernel_bf16x3(cuda, case):
     assert (gen - out).abs().max().item() < 2e-4 and not torch.equal(gen, out)
 
 
+@pytest.mark.parametrize("case", [(2, 16, 32, 64, 0, 64, 3, 3, 16128064), (1, 24, 48, 128, 128, 256, 1, 5, 16128128), (1, 13, 22, 128, 0, 128, 3, 3, 16128128)])
+def test_conv2d_halo_patch_kernel_bf16x6(cuda, case):
+    """Three-piece split on the halo patch: still at fp32 accuracy (error against a float64 convolution of the size of the
+    native kernel's)."""
+    ops = _ops()
+    B, H, W, c0, c1, co, kh, kw, tile = case
+    g = torch.Generator().manual_seed(sum(case) + 6)
+    xa = torch.randn((B, c0, H, W), generator=g)
+    xb = torch.randn((B, c1, H, W), generator=g) if c1 else None
+    ci = c0 + c1
+    w = torch.randn((co, ci, kh, kw), generator=g) / np.sqrt(ci * kh * kw)
+    b = torch.randn((co,), generator=g)
+    xin = xa if xb is None else torch.cat([xa, xb], 1)
+    ref = F.conv2d(xin.double(), w.double(), b.double(), padding=(kh // 2, kw // 2)).float()
+    wp = ops.pack_conv_weight(w).cuda()
+    kwargs = dict(shift=b.cuda(), x2=None if xb is None else nhwc(xb))
+    out32 = ops.conv2d_nhwc(nhwc(xa), wp, kh, kw, co, tile=tile, **kwargs)
+    out6 = ops.conv2d_nhwc(nhwc(xa), wp, kh, kw, co, tile=tile, precision="bf16x6", **kwargs)
+    e32 = (nchw(out32) - ref).abs().max().item()
+    e6 = (nchw(out6) - ref).abs().max().item()
+    assert e32 < 2e-5 and e6 < 2e-5 and e6 < 3 * e32 + 1e-6, (e32, e6)
+    assert not torch.equal(out6, out32)
+
+
 def test_conv2d_two_segments_residual_and_scale(cuda):
     ops = _ops()
     g = torch.Generator().manual_seed(3)
