@@ -110,12 +110,14 @@ constexpr int kKAlign = 32;   // packed weights are zero-padded along K to this 
 // same products in another summation order.  Why it matters: the rate of the general kernel follows the A bytes staged per MFMA
 // (DESIGN.md section 4), which this cuts by the number of taps.
 template <int BM, int BN, int WM, int WN, int EPI, bool NORM, int BK, int PREC, int KS = 1, bool SK = false, int MODE = 0>
-__global__ __launch_bounds__(256 * KS, (BK == 16 && KS == 1) ? (PREC == 3 ? 2 : (PREC == 0 && BM <= 128 && BN <= 128 && !NORM && EPI != OFX_EPI_FLOW) ? 4 : 3) : 1) void igemm_kernel(const ConvK p) {
+__global__ __launch_bounds__(256 * KS, (BK == 16 && KS == 1) ? (PREC == 3 ? 2 : (PREC == 0 && (BM <= 128 || MODE == 2) && BN <= 128 && !NORM && EPI != OFX_EPI_FLOW) ? 4 : 3) : 1) void igemm_kernel(const ConvK p) {
     constexpr bool UK = MODE == 1, PATCH = MODE == 2;
     // halo patch rows staged per channel slab, rounded up to whole groups of 16: 8x16 patches 12 x 16 / 10 x 18 / 8 x 20 -> 192,
     // 8x8 patches (the 64-row tile) 12 x 8 / 10 x 10 / 8 x 12 -> 112
-    constexpr int kPatchRows = BM == 128 ? 192 : 112;
-    constexpr int kPW = BM == 128 ? 16 : 8;   // patch width in pixels (its height is 8)
+    // (the 256-row tile: 16x16 patches, 20 x 16 / 18 x 18 / 16 x 20 -> 336)
+    constexpr int kPatchRows = BM == 256 ? 336 : BM == 128 ? 192 : 112;
+    constexpr int kPW = BM >= 128 ? 16 : 8;   // patch width in pixels
+    constexpr int kPH = BM / kPW;             // patch height: 8, or 16 for the 256-row tile
     constexpr int TM = WM / 32, TN = WN / 32;
     constexpr int WAVES_N = BN / WN;
     constexpr int LDK = BK + 4;               // LDS row stride in floats (144 B / 80 B): conflict-free b128 fragment reads
@@ -243,16 +245,17 @@ __global__ __launch_bounds__(256 * KS, (BK == 16 && KS == 1) ? (PREC == 3 ? 2 : 
     int pt_b = 0, pt_y0 = 0, pt_x0 = 0;
     if constexpr (PATCH) {
         const int tpr = (p.Win + kPW - 1) / kPW;           // patches per image row / per image: the last ones may hang over the map
-        const int tpi = ((p.Hin + 7) >> 3) * tpr;
+        const int tpi = ((p.Hin + kPH - 1) / kPH) * tpr;
         pt_b = mt / tpi;
         const int trem = mt - pt_b * tpi;
         const int ty = trem / tpr;
-        pt_y0 = ty * 8;
+        pt_y0 = ty * kPH;
         pt_x0 = (trem - ty * tpr) * kPW;
     }
 
     if constexpr (PATCH) {
-        static_assert(!PATCH || (PREC <= 3 && KS == 1 && ((BM == 128 && (WM == 64 || WM == 32) && BK == 16 && !SK) || (PREC == 0 && BM == 64 && WM == 32 && BK == 32))),
+        static_assert(!PATCH || (PREC <= 3 && KS == 1 && ((BM == 128 && (WM == 64 || WM == 32) && BK == 16 && !SK) || (PREC == 0 && BM == 64 && WM == 32 && BK == 32) ||
+                                                         (PREC == 0 && BM == 256 && WM == 64 && BK == 16 && !SK))),
                       "patch mode: 128-row tiles with 16-channel slabs (fp32 or bf16x3), or the fp32 64x64 small-grid tile with 32-channel slabs (split-K allowed)");
         static_assert(!PATCH || (EPI != OFX_EPI_FLOW && EPI != kEpiVolPool), "patch mode: plain / GRU epilogues");
         typedef int v4i __attribute__((ext_vector_type(4)));
@@ -285,7 +288,7 @@ __global__ __launch_bounds__(256 * KS, (BK == 16 && KS == 1) ? (PREC == 3 ? 2 : 
             const int row = PREC == 0 ? (j % kG) * kS + (j / kG) % kS + (j / (kG * kS)) * (kG * kS) : 16 * (j / 16) + 2 * (j % 8) + ((j / 8) & 1);
             const int hy = row / PWH, hx = row - hy * PWH;
             const int gy = pt_y0 - p.padH + hy, gx = pt_x0 - p.padW + hx;
-            const bool ok = j < kPatchRows && row < (8 + p.KH - 1) * PWH && (unsigned)gy < (unsigned)p.Hin && (unsigned)gx < (unsigned)p.Win;
+            const bool ok = j < kPatchRows && row < (kPH + p.KH - 1) * PWH && (unsigned)gy < (unsigned)p.Hin && (unsigned)gx < (unsigned)p.Win;
             const int pix = (pt_b * p.Hin + gy) * p.Win + gx;
             avo0[q] = ok ? pix * (p.ld0 * 4) + kq * 16 : kOOB;
             avo1[q] = ok ? pix * (p.ld1 * 4) + kq * 16 : kOOB;
@@ -1081,7 +1084,7 @@ __global__ __launch_bounds__(256 * KS, (BK == 16 && KS == 1) ? (PREC == 3 ? 2 : 
             }
         }
     };
-    if (PATCH ? (pt_y0 + 8 <= p.Hin && pt_x0 + kPW <= p.Win) : (m0 + BM <= Mrows)) epilogue(std::true_type{});
+    if (PATCH ? (pt_y0 + kPH <= p.Hin && pt_x0 + kPW <= p.Win) : (m0 + BM <= Mrows)) epilogue(std::true_type{});
     else epilogue(std::false_type{});
 }
 
@@ -1122,6 +1125,7 @@ int launch_tile_uk(const ConvK& k, int epi, bool norm, int nz, hipStream_t s) {
 template <int BM, int BN, int WM, int WN, int BK, int PREC = 0, int KS = 1, bool SK = false>
 int launch_tile(const ConvK& k, int epi, bool norm, int nz, hipStream_t s) {
     if constexpr (KS == 1 && ((PREC == 0 && BM == 128 && BK == 16 && !SK && (BN == 64 || BN == 96 || BN == 128 || BN == 192)) || (PREC == 0 && BM == 64 && BN == 64 && BK == 32) ||
+                              (PREC == 0 && BM == 256 && BN == 64 && BK == 16 && !SK) ||
                               ((PREC == 1 || PREC == 2 || PREC == 3) && BM == 128 && BK == 16 && !SK && (BN == 64 || BN == 128)))) {
         if (k.patch && epi != OFX_EPI_FLOW && epi != kEpiVolPool) return launch_tile_uk<BM, BN, WM, WN, BK, PREC, KS, SK, 2>(k, epi, norm, nz, s);
     }
@@ -1334,17 +1338,23 @@ extern "C" int ofx_conv2d_alpha(const ofx_conv_desc* d, float alpha, void* strea
     static const bool no_patch = getenv("OFX_CONV_NO_PATCH") != nullptr;
     const bool shape_ok = (d->KH == 3 && d->KW == 3) || (d->KH == 1 && d->KW == 5) || (d->KH == 5 && d->KW == 1);
     k.KH = d->KH;
-    const bool big = bm == 128 && bk == 16, small = bm == 64 && bn == 64 && bk == 32;      // 8x16 patches / 8x8 patches (small grids, split-K)
-    const int pw = big ? 16 : 8;
+    const bool big = (bm == 128 || (bm == 256 && bn == 64)) && bk == 16, small = bm == 64 && bn == 64 && bk == 32;   // 8x16 (16x16) patches / 8x8 patches (small grids, split-K)
+    const int pw = big ? 16 : 8, ph = bm == 256 ? 16 : 8;
     // the 128-row tiles also take maps that are not whole patches (the last patch of a row / column hangs over: its outside
     // pixels stage zeros and are masked in the epilogue); the small tile, whose grid feeds the split-K choice above, does not
-    const bool whole = d->Hin % 8 == 0 && d->Win % pw == 0;
+    const bool whole = d->Hin % ph == 0 && d->Win % pw == 0;
     k.patch = (!no_patch && d->precision == OFX_PREC_FP32 && shape_ok && d->stride == 1 && d->padH == d->KH / 2 && d->padW == d->KW / 2 &&
                d->Hin == d->Hout && d->Win == d->Wout && (whole || big) && k.cin % bk == 0 &&
                (d->c1 == 0 || d->c0 % bk == 0) && (!d->nmean || d->c1 == 0) && nz == 1 && (big || small) &&
                (bn == 64 || bn == 96 || bn == 128 || bn == 192) && d->epi != OFX_EPI_FLOW)
                   ? 1 : 0;
-    if (k.patch && !whole) k.mtiles = d->B * ((d->Hin + 7) / 8) * ((d->Win + 15) / 16);
+    if (k.patch && bm == 128 && bn == 64 && d->tile == 0 && d->Hin % 16 == 0 && d->Win % 16 == 0 && M / 256 >= 4096) {
+        // 64-channel layers on large maps: 16x16 patches (256x64 tile, 64x64 per wave) halve the weight staging per MFMA:
+        // 136 -> 139-143 TF on grids of four rounds or more (it loses on shorter grids: the tail is twice as coarse)
+        bm = 256;
+        k.mtiles = (int)(M / 256);
+    } else
+    if (k.patch && !whole) k.mtiles = d->B * ((d->Hin + ph - 1) / ph) * ((d->Win + 15) / 16);
     if (d->precision != OFX_PREC_FP32) {
         // split-bf16 matrix-core path (opt-in): three tiles; every other choice is mapped onto them (the ragged
         // N of a 96- or 2-channel layer is zero-filled by the descriptors)

@@ -170,7 +170,9 @@ def test_conv2d_bf16x6_mode_is_fp32_accurate(cuda, case):
     (1, 32, 32, 96, 0, 100, 3, 3, 32064064),
     # maps that are not whole 8x16 patches: the last patch of a row / column hangs over
     (2, 13, 22, 64, 0, 64, 3, 3, 16128064), (1, 65, 97, 128, 128, 128, 1, 5, 16128128), (1, 9, 40, 128, 0, 192, 5, 1, 16128192),
-    (3, 7, 5, 32, 0, 96, 3, 3, 16128096)])
+    (3, 7, 5, 32, 0, 96, 3, 3, 16128096),
+    # the 256x64 tile (tile override only): 16x16 patches, whole and overhanging
+    (2, 32, 32, 64, 0, 64, 3, 3, 16256064), (1, 40, 25, 128, 0, 64, 1, 5, 16256064)])
 def test_conv2d_halo_patch_kernel(cuda, case):
     """The halo-patch instantiation (stride-1 3x3 / 1x5 / 5x1 on maps made of whole 8x16 patches; forced here through the
     128-row tile override, the executor reaches it by itself at batch size) against F.conv2d: borders, every tile width, one
