@@ -267,6 +267,41 @@ def test_conv2d_halo_patch_kernel_bf16x6(cuda, case):
     assert not torch.equal(out6, out32)
 
 
+def test_conv2d_randomised_sweep_over_schedules(cuda):
+    """Seeded sweep: random maps, channel counts (one and two segments), filter shapes, strides and forced tiles, so that the
+    general gather, the scalar-coordinate and the halo-patch schedules (whole and overhanging patches, all patch tiles) all get
+    shapes nobody hand-picked; every result against a float64 convolution."""
+    ops = _ops()
+    rng = np.random.default_rng(2024)
+    tiles = [0, 16128128, 16128064, 16128192, 16128096, 32064064, 16064064, 16256064, 32128032]
+    shapes = [(3, 3), (1, 5), (5, 1), (1, 1), (7, 7)]
+    worst = 0.0
+    for it in range(48):
+        kh, kw = shapes[rng.integers(len(shapes))]
+        stride = int(rng.choice([1, 1, 1, 2])) if (kh, kw) in ((3, 3), (7, 7)) else 1
+        B = int(rng.integers(1, 4))
+        H, W = int(rng.integers(5, 45)), int(rng.integers(5, 50))
+        c0 = int(rng.choice([4, 16, 32, 48, 64, 96, 128]))
+        c1 = int(rng.choice([0, 0, 32, 64])) if c0 % 32 == 0 else 0
+        co = int(rng.choice([2, 24, 64, 70, 96, 128, 192, 200]))
+        tile = int(tiles[rng.integers(len(tiles))])
+        g = torch.Generator().manual_seed(1000 + it)
+        xa = torch.randn((B, c0, H, W), generator=g)
+        xb = torch.randn((B, c1, H, W), generator=g) if c1 else None
+        ci = c0 + c1
+        w = torch.randn((co, ci, kh, kw), generator=g) / np.sqrt(ci * kh * kw)
+        b = torch.randn((co,), generator=g)
+        xin = xa if xb is None else torch.cat([xa, xb], 1)
+        ref = torch.relu(F.conv2d(xin.double(), w.double(), b.double(), stride=stride, padding=(kh // 2, kw // 2))).float()
+        out = ops.conv2d_nhwc(nhwc(xa), ops.pack_conv_weight(w).cuda(), kh, kw, co, stride=stride, shift=b.cuda(), act="relu",
+                              x2=None if xb is None else nhwc(xb), tile=tile)
+        assert tuple(nchw(out).shape) == tuple(ref.shape), (it, kh, kw, stride, B, H, W, c0, c1, co, tile)
+        err = (nchw(out) - ref).abs().max().item()
+        worst = max(worst, err)
+        assert err < 3e-5, (it, err, kh, kw, stride, B, H, W, c0, c1, co, tile)
+    assert worst > 0
+
+
 def test_conv2d_two_segments_residual_and_scale(cuda):
     ops = _ops()
     g = torch.Generator().manual_seed(3)

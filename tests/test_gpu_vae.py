@@ -65,6 +65,24 @@ def test_fused_attention_masked_keys_and_large_logits(cuda):
     assert (out[:, keep] - ref[:, keep]).abs().max().item() < 5e-5
 
 
+def test_fused_attention_randomised_sweep(cuda):
+    """Seeded sweep over the fused kernel's head sizes with ragged token counts (tails of the 128-query tile, of the 32-key
+    block and of the 64-key tile), batch-head counts on and off the XCD-grouped mapping, and the three bias forms."""
+    from sd_animation_optical_flow_amd import ops
+    rng = np.random.default_rng(77)
+    for it in range(24):
+        D = int(rng.choice([40, 64, 80, 128, 160]))
+        BH = int(rng.choice([1, 3, 8, 16]))
+        Nq, Nk = int(rng.integers(1, 400)), int(rng.integers(1, 400))
+        g = torch.Generator().manual_seed(500 + it)
+        q, k, v = torch.randn((BH, Nq, D), generator=g), torch.randn((BH, Nk, D), generator=g), torch.randn((BH, Nk, D), generator=g)
+        mode = it % 3
+        bias = None if mode == 0 else torch.randn((Nq, Nk), generator=g) if mode == 1 else torch.randn((BH, Nq, Nk), generator=g)
+        ref = VO.attention(q, k, v, bias)
+        out = ops.attention(q.cuda(), k.cuda(), v.cuda(), None if bias is None else bias.cuda()).cpu()
+        assert (out - ref).abs().max().item() < 3e-5, (it, BH, Nq, Nk, D, mode)
+
+
 def test_xformers_shim_on_the_device(cuda):
     """The call exactly as ldm/modules/attention.py:314 makes it: [b*heads, n, dim_head] half tensors and a 2-D bias."""
     import xformers.ops
