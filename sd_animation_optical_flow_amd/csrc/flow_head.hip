@@ -17,13 +17,14 @@ struct FlowHeadArgs {
     int ldx, ldh, Kpad, h, w_, M;
 };
 
-constexpr int kPW = 8;   // output pixels per wavefront strip
+constexpr int kPW = 8;   // output pixels per strip row
+constexpr int kPR = 2;   // output rows per strip
 
-// One wavefront produces a strip of kPW horizontally adjacent pixels: the 3 x (kPW+2) input rows it needs
-// are each loaded once (3.75 row reads per output pixel instead of 9) and every loaded row feeds the three
-// horizontal taps it belongs to.  Lane l owns input channels 4l..4l+3 of all nine taps and both outputs
-// (72 weights in registers); the 2*kPW partial sums are reduced across the 64 lanes with a transposing
-// butterfly (17 cross-lane exchanges per strip instead of 6 per value).
+// One wavefront produces a strip of kPR x kPW adjacent pixels: the (kPR + 2) x (kPW + 2) input pixels it needs are each loaded
+// once (2.5 pixel reads per output pixel instead of 9; 3.75 with one-row strips) and every loaded pixel feeds all the taps it
+// belongs to.  Lane l owns input channels 4l..4l+3 of all nine taps and both outputs (72 weights in registers); the
+// 2 * kPR * kPW = 32 partial sums are reduced across the 64 lanes with a transposing butterfly (31 + 1 cross-lane exchanges per
+// strip instead of 6 per value).
 __global__ __launch_bounds__(256, 3) void flow_head_kernel(const FlowHeadArgs a) {
     const int lane = threadIdx.x & 63;
     const int gw = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;      // global wave id
@@ -35,21 +36,25 @@ __global__ __launch_bounds__(256, 3) void flow_head_kernel(const FlowHeadArgs a)
         w1[t] = *reinterpret_cast<const float4*>(a.w + a.Kpad + t * 256 + lane * 4);
     }
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, (short)0, a.M * a.ldx * 4, 0x00020000);
-    const int spr = (a.w_ + kPW - 1) / kPW;          // strips per image row
-    const int nstrips = (a.M / a.w_) * spr;          // M = B*h*w
+    const int spr = (a.w_ + kPW - 1) / kPW;          // strips per strip row
+    const int rpi = (a.h + kPR - 1) / kPR;           // strip rows per image
+    const int nimg = a.M / (a.h * a.w_);
+    const int nstrips = nimg * rpi * spr;
     for (int sidx = gw; sidx < nstrips; sidx += nw) {
-        const int row = sidx / spr;                  // b*h + y
-        const int x0 = (sidx - row * spr) * kPW;
-        const int y = row % a.h;
-        float acc[2 * kPW];
+        const int srow = sidx / spr;                 // image * rpi + strip row
+        const int x0 = (sidx - srow * spr) * kPW;
+        const int img = srow / rpi;
+        const int y0 = (srow - img * rpi) * kPR;     // first output row of the strip
+        const int row0 = img * a.h + y0;             // b*h + y of that row
+        float acc[2 * kPR * kPW];                    // [output row][pixel][output]
 #pragma unroll
-        for (int i = 0; i < 2 * kPW; ++i) acc[i] = 0.f;
+        for (int i = 0; i < 2 * kPR * kPW; ++i) acc[i] = 0.f;
         // rows are read through a buffer descriptor: one VGPR offset (lane * 16), the pixel as a scalar
         // offset, out-of-image taps as an out-of-range offset (the hardware returns 0)
 #pragma unroll
-        for (int ky = 0; ky < 3; ++ky) {
-            const bool yin = (unsigned)(y + ky - 1) < (unsigned)a.h;                       // wave-uniform
-            const int pix0 = (row + ky - 1) * a.w_ + x0 - 1;
+        for (int r = 0; r < kPR + 2; ++r) {          // input row y0 - 1 + r
+            const bool yin = (unsigned)(y0 + r - 1) < (unsigned)a.h;                       // wave-uniform
+            const int pix0 = (row0 + r - 1) * a.w_ + x0 - 1;
             float4 v[kPW + 2];
 #pragma unroll
             for (int c = 0; c < kPW + 2; ++c) {
@@ -58,64 +63,77 @@ __global__ __launch_bounds__(256, 3) void flow_head_kernel(const FlowHeadArgs a)
                 v[c] = make_float4(__uint_as_float(raw[0]), __uint_as_float(raw[1]), __uint_as_float(raw[2]), __uint_as_float(raw[3]));
             }
 #pragma unroll
-            for (int c = 0; c < kPW + 2; ++c)
+            for (int oy = 0; oy < kPR; ++oy) {
+                const int ky = r - oy;               // output row y0 + oy reads input row y0 + oy + ky - 1
+                if (ky < 0 || ky > 2) continue;
 #pragma unroll
-                for (int kx = 0; kx < 3; ++kx) {
-                    const int j = c - kx;            // output pixel x0 + j reads input column x0 + j + kx - 1 = x0 + c - 1
-                    if (j < 0 || j >= kPW) continue;
-                    const float4 q0 = w0[ky * 3 + kx], q1 = w1[ky * 3 + kx];
-                    float s0 = acc[2 * j], s1 = acc[2 * j + 1];
-                    s0 = fmaf(v[c].x, q0.x, s0); s0 = fmaf(v[c].y, q0.y, s0); s0 = fmaf(v[c].z, q0.z, s0); s0 = fmaf(v[c].w, q0.w, s0);
-                    s1 = fmaf(v[c].x, q1.x, s1); s1 = fmaf(v[c].y, q1.y, s1); s1 = fmaf(v[c].z, q1.z, s1); s1 = fmaf(v[c].w, q1.w, s1);
-                    acc[2 * j] = s0;
-                    acc[2 * j + 1] = s1;
-                }
+                for (int c = 0; c < kPW + 2; ++c)
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx) {
+                        const int j = c - kx;        // output pixel x0 + j reads input column x0 + j + kx - 1 = x0 + c - 1
+                        if (j < 0 || j >= kPW) continue;
+                        const float4 q0 = w0[ky * 3 + kx], q1 = w1[ky * 3 + kx];
+                        float s0 = acc[(oy * kPW + j) * 2], s1 = acc[(oy * kPW + j) * 2 + 1];
+                        s0 = fmaf(v[c].x, q0.x, s0); s0 = fmaf(v[c].y, q0.y, s0); s0 = fmaf(v[c].z, q0.z, s0); s0 = fmaf(v[c].w, q0.w, s0);
+                        s1 = fmaf(v[c].x, q1.x, s1); s1 = fmaf(v[c].y, q1.y, s1); s1 = fmaf(v[c].z, q1.z, s1); s1 = fmaf(v[c].w, q1.w, s1);
+                        acc[(oy * kPW + j) * 2] = s0;
+                        acc[(oy * kPW + j) * 2 + 1] = s1;
+                    }
+            }
         }
         // transposing butterfly: after the step with distance d the lane keeps half of its values, chosen by
-        // its bit d; 16 -> 8 -> 4 -> 2 -> 1 values, then two plain steps.  Lane l (l & 3 == 0) ends with the
-        // full sum of value id = bit5*8 + bit4*4 + bit3*2 + bit2.
-        static_assert(kPW == 8, "the butterfly below is written for 16 values");
-        float r8[8], r4[4], r2[2], r1;
+        // its bit d; 32 -> 16 -> 8 -> 4 -> 2 -> 1 values, then one plain step.  Lane l ends with the full sum of value
+        // id = bit5*16 + bit4*8 + bit3*4 + bit2*2 + bit1.
+        static_assert(kPW == 8 && kPR == 2, "the butterfly below is written for 32 values");
+        float r16[16], r8[8], r4[4], r2[2], r1;
         {
             const bool hi = (lane & 32) != 0;
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const float send = hi ? acc[i] : acc[i + 8];
-                const float keep = hi ? acc[i + 8] : acc[i];
-                r8[i] = keep + __shfl_xor(send, 32, 64);
+            for (int i = 0; i < 16; ++i) {
+                const float send = hi ? acc[i] : acc[i + 16];
+                const float keep = hi ? acc[i + 16] : acc[i];
+                r16[i] = keep + __shfl_xor(send, 32, 64);
             }
         }
         {
             const bool hi = (lane & 16) != 0;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const float send = hi ? r8[i] : r8[i + 4];
-                const float keep = hi ? r8[i + 4] : r8[i];
-                r4[i] = keep + __shfl_xor(send, 16, 64);
+            for (int i = 0; i < 8; ++i) {
+                const float send = hi ? r16[i] : r16[i + 8];
+                const float keep = hi ? r16[i + 8] : r16[i];
+                r8[i] = keep + __shfl_xor(send, 16, 64);
             }
         }
         {
             const bool hi = (lane & 8) != 0;
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const float send = hi ? r4[i] : r4[i + 2];
-                const float keep = hi ? r4[i + 2] : r4[i];
-                r2[i] = keep + __shfl_xor(send, 8, 64);
+            for (int i = 0; i < 4; ++i) {
+                const float send = hi ? r8[i] : r8[i + 4];
+                const float keep = hi ? r8[i + 4] : r8[i];
+                r4[i] = keep + __shfl_xor(send, 8, 64);
             }
         }
         {
             const bool hi = (lane & 4) != 0;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const float send = hi ? r4[i] : r4[i + 2];
+                const float keep = hi ? r4[i + 2] : r4[i];
+                r2[i] = keep + __shfl_xor(send, 4, 64);
+            }
+        }
+        {
+            const bool hi = (lane & 2) != 0;
             const float send = hi ? r2[0] : r2[1];
             const float keep = hi ? r2[1] : r2[0];
-            r1 = keep + __shfl_xor(send, 4, 64);
+            r1 = keep + __shfl_xor(send, 2, 64);
         }
-        r1 += __shfl_xor(r1, 2, 64);
         r1 += __shfl_xor(r1, 1, 64);
-        const int id = ((lane >> 5) & 1) * 8 + ((lane >> 4) & 1) * 4 + ((lane >> 3) & 1) * 2 + ((lane >> 2) & 1);
-        const int j = id >> 1, o = id & 1;
-        const int x = x0 + j;
-        if ((lane & 3) == 0 && x < a.w_) {
-            const long m = (long)row * a.w_ + x;
+        const int id = ((lane >> 5) & 1) * 16 + ((lane >> 4) & 1) * 8 + ((lane >> 3) & 1) * 4 + ((lane >> 2) & 1) * 2 + ((lane >> 1) & 1);
+        const int oy = id >> 4, j = (id >> 1) & 7, o = id & 1;
+        const int x = x0 + j, y = y0 + oy;
+        if ((lane & 1) == 0 && x < a.w_ && y < a.h) {
+            const long m = (long)(row0 + oy) * a.w_ + x;
             const float c1 = a.coords1[m * 2 + o] + r1 + a.bias[o];
             a.coords1[m * 2 + o] = c1;
             const float fl = c1 - (float)(o == 0 ? x : y);
@@ -135,7 +153,7 @@ int ofx_flow_head_launch(const float* x, int ldx, const float* w, int Kpad, cons
     const long M = (long)B * h * w_;
     OFX_REQUIRE(M * ldx * 4 < (1L << 31) - 64, OFX_EINVAL);      // 32-bit byte offsets into x
     a.M = (int)M;
-    const long strips = (M / w_) * ((w_ + kPW - 1) / kPW);
+    const long strips = (long)B * ((h + kPR - 1) / kPR) * ((w_ + kPW - 1) / kPW);
     const int blocks = (int)std::min<long>((strips + 3) / 4, 256L * 16);   // one strip per wavefront, grid-stride beyond 16 workgroups per CU
     OfxProfScope prof("flow_head", s);
     hipLaunchKernelGGL(flow_head_kernel, dim3(blocks), dim3(256), 0, s, a);
