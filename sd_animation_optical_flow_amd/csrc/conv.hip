@@ -83,6 +83,7 @@ struct ConvK {
     unsigned kw1_mask;              // all ones when KW == 1 (then tap / KW = tap), else 0
     int uk;                         // every BK chunk inside one tap and one segment: scalar chunk coordinates (MODE 1)
     int KH, patch;                  // patch: the layer qualifies for the halo-patch kernel (MODE 2)
+    float* stats;                   // plain epilogue: per (M tile, wave row) and channel, (sum, sum of squares) of the stored values
     int bytes0, bytes1, bytesw;     // extents of the two input segments and of the weight matrix (per z)
     // kEpiVolPool (correlation volume): level 1 of the pyramid written from the accumulators (see the epilogue)
     float* pool_out; long pool_zs; int pool_wb0, pool_wb1, pool_slice1;
@@ -1012,6 +1013,8 @@ __global__ __launch_bounds__(256 * KS, (BK == 16 && KS == 1) ? (PREC == 3 ? 2 : 
                     rs_p = __builtin_amdgcn_make_buffer_rsrc((void*)(p.pool_out + (long)z * p.pool_zs), (short)0, (int)((long)Mrows * p.pool_slice1 * 4), 0x00020000);
                     vo_p = ((mb0 * p.pool_slice1 + idx1) * 4) | (pool_lane ? 0 : kOOB);
                 }
+                const bool do_stats = EPK == OFX_EPI_PLAIN && !TRANSC && !VOLPOOL && p.stats != nullptr;
+                float st_s = 0.0f, st_q = 0.0f;                 // this lane's column over the wave's WM rows (its 16 * TM elements)
 #pragma unroll
                 for (int ib = 0; ib < TM * (16 / EB); ++ib) {
                     // EB elements per phase: enough loads in flight to cover the latency, few enough live
@@ -1074,10 +1077,29 @@ __global__ __launch_bounds__(256 * KS, (BK == 16 && KS == 1) ? (PREC == 3 ? 2 : 
                             v[q] = (1.0f - x1[q]) * x2[q] + x1[q] * ofx_tanh(v[q]);
                         }
                         stf(v[q], rs_w, vo_w | mask_of(row_of(q)), srow(q) * ldw * 4);
+                        if constexpr (EPK == OFX_EPI_PLAIN && !TRANSC && !VOLPOOL) {
+                            if (do_stats) {                    // wave-uniform
+                                const float vv = (FULL || mask_of(row_of(q)) == 0) ? v[q] : 0.0f;
+                                st_s += vv;
+                                st_q = fmaf(vv, vv, st_q);
+                            }
+                        }
                         if constexpr (VOLPOOL) {
                             const float s1 = v[q] + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v[q]), 0xB1, 0xF, 0xF, false));   // quad_perm [1,0,3,2]: lane ^ 1
                             const float s2 = s1 + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(s1), 0x128, 0xF, 0xF, false));    // row_ror:8: lane ^ 8
                             stf(s2 * 0.25f, rs_p, vo_p | mask_of(row_of(q)), srow(q) * p.pool_slice1 * 4);
+                        }
+                    }
+                }
+                if constexpr (EPK == OFX_EPI_PLAIN && !TRANSC && !VOLPOOL) {
+                    if (do_stats) {
+                        // the two lane halves hold the other rows of the same column
+                        st_s += __shfl_xor(st_s, 32, 64);
+                        st_q += __shfl_xor(st_q, 32, 64);
+                        if (lane < 32 && nok) {
+                            float* o = p.stats + (((long)mt * (BM / WM) + wm) * p.Cout + n) * 2;
+                            o[0] = st_s;
+                            o[1] = st_q;
                         }
                     }
                 }
@@ -1145,9 +1167,33 @@ struct VolPool {            // set by ofx_conv2d_volpool around one ofx_conv2d_a
     int wb0 = 0, wb1 = 0, slice1 = 0;
 };
 thread_local VolPool tl_pool;
+
+// Instance-norm statistics from the accumulators (set by ofx_conv2d_stats around one ofx_conv2d call): every wave of a tile writes
+// the per-channel sum and sum of squares of its WM rows; a finalize kernel adds them per image in a fixed order.  Saves the
+// statistics pass over the tensor the convolution has just written.
+struct StatsReq {
+    bool on = false;
+    float* part = nullptr;
+    size_t cap_floats = 0;
+    int rows_per_image = 0;     // out: 0 = not produced (the caller falls back to ofx_inorm_stats)
+};
+thread_local StatsReq tl_stats;
 }  // namespace
 
 extern "C" int ofx_conv2d(const ofx_conv_desc* d, void* stream) { return ofx_conv2d_alpha(d, 1.0f, stream); }
+
+// ofx_conv2d that also leaves, when the launch qualifies, the per-wave (sum, sum of squares) of every output channel in `part`
+// ([B][rows_per_image][Cout][2] floats) for ofx_inorm_finalize_part; *rows_per_image = 0 means "not produced".
+int ofx_conv2d_stats(const ofx_conv_desc* d, float* part, size_t part_floats, int* rows_per_image, void* stream) {
+    tl_stats.on = true;
+    tl_stats.part = part;
+    tl_stats.cap_floats = part_floats;
+    tl_stats.rows_per_image = 0;
+    const int st = ofx_conv2d_alpha(d, 1.0f, stream);
+    *rows_per_image = st ? 0 : tl_stats.rows_per_image;
+    tl_stats = StatsReq{};
+    return st;
+}
 
 // Correlation volume in the blocked layout + pyramid level 1 from the accumulators (corr.hip decides when it applies:
 // fp32, 128x128 tiles, h % 8 == 0 and w % 16 == 0 so that level 1 is tiled by whole blocks).  pool_out: level 1,
@@ -1355,6 +1401,21 @@ extern "C" int ofx_conv2d_alpha(const ofx_conv_desc* d, float alpha, void* strea
         k.mtiles = (int)(M / 256);
     } else
     if (k.patch && !whole) k.mtiles = d->B * ((d->Hin + ph - 1) / ph) * ((d->Win + 15) / 16);
+    // statistics from the accumulators (ofx_conv2d_stats): raw outputs only, tiles that stay inside one image
+    k.stats = nullptr;
+    if (tl_stats.on) {
+        tl_stats.rows_per_image = 0;
+        const int waves_m = (bm == 256 && bn == 64) ? 4 : (bm == 128 && (bn == 128 || bn == 64 || bn == 192)) ? 2 : (bm == 128 && (bn == 96 || bn == 32)) ? 4
+                            : (bm == 64 && bn == 64) ? 2 : 0;
+        const long hw = (long)d->Hout * d->Wout;
+        const bool ok = waves_m && d->precision == OFX_PREC_FP32 && d->epi == OFX_EPI_PLAIN && d->act == OFX_ACT_NONE && !d->res && nz == 1 &&
+                        k.mtiles % d->B == 0 && (k.patch || hw % bm == 0);
+        const long rows = ok ? (long)(k.mtiles / d->B) * waves_m : 0;
+        if (ok && (size_t)d->B * rows * d->Cout * 2 <= tl_stats.cap_floats) {
+            k.stats = tl_stats.part;
+            tl_stats.rows_per_image = (int)rows;
+        }
+    }
     if (d->precision != OFX_PREC_FP32) {
         // split-bf16 matrix-core path (opt-in): three tiles; every other choice is mapped onto them (the ragged
         // N of a 96- or 2-channel layer is zero-filled by the descriptors)

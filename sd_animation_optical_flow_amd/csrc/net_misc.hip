@@ -99,6 +99,40 @@ __global__ __launch_bounds__(256) void inorm_finalize_kernel(const double* __res
     rstd[i] = (float)(1.0 / sqrt(var + (double)eps));
 }
 
+// The same finalisation for statistics that come out of the convolution epilogue (conv.hip, ofx_conv2d_stats): `part` holds, per
+// image, `rows` rows of [C][2] floats (sum, sum of squares over the 32 or 64 tile rows of one wave).  One workgroup per (image, 4
+// channels): thread t adds the rows t / 4, t / 4 + 64, ... of channel t % 4 in f64 (a single pair has thousands of rows and
+// only a few images: the work has to spread over rows), then the 64 partial sums of a channel are added through LDS in a fixed
+// order.
+__global__ __launch_bounds__(256) void inorm_finalize_part_kernel(const float* __restrict__ part, float* __restrict__ mean,
+                                                                  float* __restrict__ rstd, long HW, int C, float eps, int rows) {
+    __shared__ double red[256 * 2];
+    const int b = blockIdx.y;
+    const int c = blockIdx.x * 4 + (threadIdx.x & 3), g = threadIdx.x >> 2;
+    double s = 0, q = 0;
+    if (c < C)
+        for (int r = g; r < rows; r += 64) {
+            const float2 v = *reinterpret_cast<const float2*>(part + (((long)b * rows + r) * C + c) * 2);
+            s += (double)v.x;
+            q += (double)v.y;
+        }
+    red[threadIdx.x * 2] = s;
+    red[threadIdx.x * 2 + 1] = q;
+    __syncthreads();
+    if (threadIdx.x >= 4 || c >= C) return;
+    s = 0; q = 0;
+    for (int g2 = 0; g2 < 64; ++g2) {
+        s += red[(g2 * 4 + threadIdx.x) * 2];
+        q += red[(g2 * 4 + threadIdx.x) * 2 + 1];
+    }
+    const int i = b * C + c;
+    const double mu = s / (double)HW;
+    double var = q / (double)HW - mu * mu;
+    if (var < 0) var = 0;
+    mean[i] = (float)mu;
+    rstd[i] = (float)(1.0 / sqrt(var + (double)eps));
+}
+
 __global__ __launch_bounds__(256) void inorm_apply_kernel(const float* __restrict__ x, const float* __restrict__ mean,
                                                           const float* __restrict__ rstd, const float* __restrict__ res,
                                                           const float* __restrict__ rmean, const float* __restrict__ rrstd,
@@ -309,3 +343,11 @@ int ofx_upsample_flow(const float* coords1, const float* mask, float* flow_up, i
 }
 
 }  // extern "C"
+
+int ofx_inorm_finalize_part(const float* part, float* mean, float* rstd, int B, int rows, long HW, int C, float eps, hipStream_t s) {
+    OFX_REQUIRE(part && mean && rstd && B > 0 && rows > 0 && HW > 0 && C > 0, OFX_EINVAL);
+    OfxProfScope prof("inorm_finalize", s);
+    hipLaunchKernelGGL(inorm_finalize_part_kernel, dim3(ofx_cdiv(C, 4), B), dim3(256), 0, s, part, mean, rstd, HW, C, eps, rows);
+    return ofx_launch_status();
+}
+

@@ -42,6 +42,11 @@ extern "C" int ofx_conv2d_alpha(const ofx_conv_desc* d, float alpha, void* strea
 // conv.hip: the blocked correlation volume GEMM that also writes pyramid level 1 from its accumulators
 int ofx_conv2d_volpool(const ofx_conv_desc* d, float alpha, float* pool_out, long pool_zs, int wb0, int wb1, int slice1, void* stream);
 
+// conv.hip / net_misc.hip: instance-norm statistics out of the convolution epilogue (rows_per_image = 0: not produced, use
+// ofx_inorm_stats) and their per-image reduction
+int ofx_conv2d_stats(const ofx_conv_desc* d, float* part, size_t part_floats, int* rows_per_image, void* stream);
+int ofx_inorm_finalize_part(const float* part, float* mean, float* rstd, int B, int rows, long HW, int C, float eps, hipStream_t s);
+
 // attn_flash.hip: fused attention for the UNet's head sizes (no workspace)
 bool ofx_attention_flash_ok(int D);
 int ofx_attention_flash_launch(const float* q, const float* k, const float* v, const float* bias, long bias_bstride, float* out, int BH, int Nq,

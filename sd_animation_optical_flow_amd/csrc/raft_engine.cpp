@@ -19,6 +19,8 @@
 // and broadcast through a zero batch stride of the correlation GEMM.
 #include "ofx_internal.h"
 
+#include <cstdlib>
+
 #include <algorithm>
 #include <cmath>
 #include <cstring>
@@ -277,6 +279,9 @@ struct Launcher {
     int precision = OFX_PREC_FP32;   // sticky: OFX_PREC_BF16X3 when the forward was asked for the split-bf16 mode
     void* sk_ws = nullptr;           // split-K scratch of the stream this launcher feeds (null: never split)
     size_t sk_bytes = 0;
+    float* stats_part = nullptr;     // consumed by the next conv(): instance-norm partial sums out of its epilogue (conv.hip)
+    size_t stats_floats = 0;
+    int stats_rows = 0;              // set by that conv(): rows per image in stats_part, 0 = not produced
     // generic conv launch; all pointer plumbing in one place
     void conv(const ConvW& c, const float* in0, int ld0, int c0, const float* in1, int ld1, int c1, float* out, int ldo,
               int B, int Hin, int Win, int stride, int act, int epi = OFX_EPI_PLAIN, const float* res = nullptr,
@@ -309,7 +314,10 @@ struct Launcher {
         d.splitk_ws = sk_ws; d.splitk_ws_bytes = sk_bytes;
         if (c0 + c1 != c.cin_pad) { st = OFX_EKEY; return; }
         ofx_prof_set_tag(c.name.c_str());
-        st = ofx_conv2d(&d, s);
+        stats_rows = 0;
+        if (stats_part) st = ofx_conv2d_stats(&d, stats_part, stats_floats, &stats_rows, s);
+        else st = ofx_conv2d(&d, s);
+        stats_part = nullptr;
         ofx_prof_set_tag(nullptr);
     }
 };
@@ -341,6 +349,8 @@ struct EncBufs {
     float *x0, *X, *Y, *R1, *R2, *R3;
     float* stats;     // 6 x [chunk][128] floats (mean/rstd for up to 3 norms)
     float* scratch;   // inorm partial sums
+    float* spart;     // instance-norm partial sums written by the convolution epilogues: [chunk][rows][C][2]
+    size_t spart_floats;
 };
 
 }  // namespace
@@ -361,13 +371,23 @@ static int run_encoder(ofx_raft* r, const std::string& enc, bool bn, const uint8
     auto C = [&](const std::string& k) -> const ConvW& { return r->convs[enc + "." + k]; };
     int st = ofx_preprocess_u8(imgs, eb.x0, (long)n * H * W, bgr, s);
     if (st) return st;
+    // statistics of the tensor the conv() just before has written: from its epilogue's partial sums when it produced them
     auto stats = [&](const float* x, long HW, int ch, float* mean, float* rstd) {
         if (L.st) return;
-        L.st = ofx_inorm_stats(x, ch, mean, rstd, eb.scratch, n, HW, ch, 1e-5f, s);
+        if (L.stats_rows > 0) L.st = ofx_inorm_finalize_part(eb.spart, mean, rstd, n, L.stats_rows, HW, ch, 1e-5f, s);
+        else L.st = ofx_inorm_stats(x, ch, mean, rstd, eb.scratch, n, HW, ch, 1e-5f, s);
+        L.stats_rows = 0;
+    };
+    static const bool no_epi_stats = getenv("OFX_NO_EPI_STATS") != nullptr;     // diagnostic: always the separate statistics pass
+    auto want_stats = [&]() {
+        if (no_epi_stats) return;
+        L.stats_part = eb.spart;
+        L.stats_floats = eb.spart_floats;
     };
     float* X = eb.X;
     float* Y = eb.Y;
     if (!bn) {
+        want_stats();
         L.conv(C("conv1"), eb.x0, 4, 4, nullptr, 0, 0, eb.R1, 64, n, H, W, 2, OFX_ACT_NONE);
         stats(eb.R1, (long)H2 * W2, 64, m1, s1);
         if (!L.st) L.st = ofx_inorm_apply(eb.R1, m1, s1, nullptr, nullptr, nullptr, X, n, (long)H2 * W2, 64, 1, s);
@@ -383,13 +403,16 @@ static int run_encoder(ofx_raft* r, const std::string& enc, bool bn, const uint8
             const int ho = hin / stride, wo = win / stride;
             const std::string p = "layer" + std::to_string(li) + "." + std::to_string(bi);
             if (!bn) {
+                want_stats();
                 L.conv(C(p + ".conv1"), X, cin, cin, nullptr, 0, 0, eb.R1, dim, n, hin, win, stride, OFX_ACT_NONE);
                 stats(eb.R1, (long)ho * wo, dim, m1, s1);
                 // norm1 + ReLU fused into conv2's operand load
+                want_stats();
                 L.conv(C(p + ".conv2"), eb.R1, dim, dim, nullptr, 0, 0, eb.R2, dim, n, ho, wo, 1, OFX_ACT_NONE,
                        OFX_EPI_PLAIN, nullptr, 0, m1, s1);
                 stats(eb.R2, (long)ho * wo, dim, m2, s2);
                 if (stride == 2) {
+                    want_stats();
                     L.conv(C(p + ".down"), X, cin, cin, nullptr, 0, 0, eb.R3, dim, n, hin, win, 2, OFX_ACT_NONE);
                     stats(eb.R3, (long)ho * wo, dim, m3, s3);
                     if (!L.st) L.st = ofx_inorm_apply(eb.R2, m2, s2, eb.R3, m3, s3, Y, n, (long)ho * wo, dim, 1, s);
@@ -463,6 +486,9 @@ static RaftWs carve(void* base, size_t cap, int B, int H, int W, int flags, int 
         eb.R3 = c.take((size_t)nch * (H / 4) * (W / 4) * 96);
         eb.stats = c.take((size_t)6 * ENC_CHUNK * 128);
         eb.scratch = c.take((size_t)ENC_CHUNK * 64 * 128 * 2 * 2);   // doubles: chunk x slices x C x {sum, sumsq}
+        // one (sum, sumsq) pair per channel and 32 tile rows at most: the half-resolution 64-channel stage bounds it
+        eb.spart_floats = (size_t)nch * (H / 2) * (W / 2) * 4 + 4096;
+        eb.spart = c.take(eb.spart_floats);
     }
     long n1 = (flags & OFX_RAFT_SHARED_IMG1) ? 1 : B, n2 = (flags & OFX_RAFT_SHARED_IMG2) ? 1 : B;
     if (n_images > 0) {
