@@ -25,7 +25,7 @@ constexpr int kPR = 2;   // output rows per strip
 // belongs to.  Lane l owns input channels 4l..4l+3 of all nine taps and both outputs (72 weights in registers); the
 // 2 * kPR * kPW = 32 partial sums are reduced across the 64 lanes with a transposing butterfly (31 + 1 cross-lane exchanges per
 // strip instead of 6 per value).
-__global__ __launch_bounds__(256, 3) void flow_head_kernel(const FlowHeadArgs a) {
+__global__ __launch_bounds__(256, 2) void flow_head_kernel(const FlowHeadArgs a) {
     const int lane = threadIdx.x & 63;
     const int gw = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;      // global wave id
     const int nw = (gridDim.x * blockDim.x) >> 6;
