@@ -18,13 +18,13 @@ struct FlowHeadArgs {
 };
 
 constexpr int kPW = 8;   // output pixels per strip row
-constexpr int kPR = 2;   // output rows per strip
+constexpr int kPR = 4;   // output rows per strip
 
 // One wavefront produces a strip of kPR x kPW adjacent pixels: the (kPR + 2) x (kPW + 2) input pixels it needs are each loaded
-// once (2.5 pixel reads per output pixel instead of 9; 3.75 with one-row strips) and every loaded pixel feeds all the taps it
+// once (1.9 pixel reads per output pixel instead of 9; 3.75 with one-row strips, 2.5 with two-row ones) and every loaded pixel feeds all the taps it
 // belongs to.  Lane l owns input channels 4l..4l+3 of all nine taps and both outputs (72 weights in registers); the
-// 2 * kPR * kPW = 32 partial sums are reduced across the 64 lanes with a transposing butterfly (31 + 1 cross-lane exchanges per
-// strip instead of 6 per value).
+// 2 * kPR * kPW = 64 partial sums are reduced across the 64 lanes with a transposing butterfly (63 cross-lane exchanges per
+// strip instead of 6 per value); every lane ends up with one finished output.
 __global__ __launch_bounds__(256, 2) void flow_head_kernel(const FlowHeadArgs a) {
     const int lane = threadIdx.x & 63;
     const int gw = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;      // global wave id
@@ -82,57 +82,64 @@ __global__ __launch_bounds__(256, 2) void flow_head_kernel(const FlowHeadArgs a)
             }
         }
         // transposing butterfly: after the step with distance d the lane keeps half of its values, chosen by
-        // its bit d; 32 -> 16 -> 8 -> 4 -> 2 -> 1 values, then one plain step.  Lane l ends with the full sum of value
-        // id = bit5*16 + bit4*8 + bit3*4 + bit2*2 + bit1.
-        static_assert(kPW == 8 && kPR == 2, "the butterfly below is written for 32 values");
-        float r16[16], r8[8], r4[4], r2[2], r1;
+        // its bit d; 64 -> 32 -> 16 -> 8 -> 4 -> 2 -> 1 values.  Lane l ends with the full sum of value id = l.
+        static_assert(kPW == 8 && kPR == 4, "the butterfly below is written for 64 values");
+        float r32[32], r16[16], r8[8], r4[4], r2[2], r1;
         {
             const bool hi = (lane & 32) != 0;
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const float send = hi ? acc[i] : acc[i + 16];
-                const float keep = hi ? acc[i + 16] : acc[i];
-                r16[i] = keep + __shfl_xor(send, 32, 64);
+            for (int i = 0; i < 32; ++i) {
+                const float send = hi ? acc[i] : acc[i + 32];
+                const float keep = hi ? acc[i + 32] : acc[i];
+                r32[i] = keep + __shfl_xor(send, 32, 64);
             }
         }
         {
             const bool hi = (lane & 16) != 0;
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const float send = hi ? r16[i] : r16[i + 8];
-                const float keep = hi ? r16[i + 8] : r16[i];
-                r8[i] = keep + __shfl_xor(send, 16, 64);
+            for (int i = 0; i < 16; ++i) {
+                const float send = hi ? r32[i] : r32[i + 16];
+                const float keep = hi ? r32[i + 16] : r32[i];
+                r16[i] = keep + __shfl_xor(send, 16, 64);
             }
         }
         {
             const bool hi = (lane & 8) != 0;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const float send = hi ? r8[i] : r8[i + 4];
-                const float keep = hi ? r8[i + 4] : r8[i];
-                r4[i] = keep + __shfl_xor(send, 8, 64);
+            for (int i = 0; i < 8; ++i) {
+                const float send = hi ? r16[i] : r16[i + 8];
+                const float keep = hi ? r16[i + 8] : r16[i];
+                r8[i] = keep + __shfl_xor(send, 8, 64);
             }
         }
         {
             const bool hi = (lane & 4) != 0;
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const float send = hi ? r4[i] : r4[i + 2];
-                const float keep = hi ? r4[i + 2] : r4[i];
-                r2[i] = keep + __shfl_xor(send, 4, 64);
+            for (int i = 0; i < 4; ++i) {
+                const float send = hi ? r8[i] : r8[i + 4];
+                const float keep = hi ? r8[i + 4] : r8[i];
+                r4[i] = keep + __shfl_xor(send, 4, 64);
             }
         }
         {
             const bool hi = (lane & 2) != 0;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const float send = hi ? r4[i] : r4[i + 2];
+                const float keep = hi ? r4[i + 2] : r4[i];
+                r2[i] = keep + __shfl_xor(send, 2, 64);
+            }
+        }
+        {
+            const bool hi = (lane & 1) != 0;
             const float send = hi ? r2[0] : r2[1];
             const float keep = hi ? r2[1] : r2[0];
-            r1 = keep + __shfl_xor(send, 2, 64);
+            r1 = keep + __shfl_xor(send, 1, 64);
         }
-        r1 += __shfl_xor(r1, 1, 64);
-        const int id = ((lane >> 5) & 1) * 16 + ((lane >> 4) & 1) * 8 + ((lane >> 3) & 1) * 4 + ((lane >> 2) & 1) * 2 + ((lane >> 1) & 1);
+        const int id = lane;
         const int oy = id >> 4, j = (id >> 1) & 7, o = id & 1;
         const int x = x0 + j, y = y0 + oy;
-        if ((lane & 1) == 0 && x < a.w_ && y < a.h) {
+        if (x < a.w_ && y < a.h) {
             const long m = (long)(row0 + oy) * a.w_ + x;
             const float c1 = a.coords1[m * 2 + o] + r1 + a.bias[o];
             a.coords1[m * 2 + o] = c1;
