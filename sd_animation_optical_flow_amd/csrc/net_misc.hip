@@ -133,33 +133,43 @@ __global__ __launch_bounds__(256) void inorm_finalize_part_kernel(const float* _
     rstd[i] = (float)(1.0 / sqrt(var + (double)eps));
 }
 
+// grid (slices, B), block = a multiple of C / 4 threads: a thread keeps one channel quad of one image for its whole loop, so its
+// mean / rstd are loaded once and the element loop has no index arithmetic beyond an add (the first version divided a 64-bit
+// index three times per float4)
 __global__ __launch_bounds__(256) void inorm_apply_kernel(const float* __restrict__ x, const float* __restrict__ mean,
                                                           const float* __restrict__ rstd, const float* __restrict__ res,
                                                           const float* __restrict__ rmean, const float* __restrict__ rrstd,
-                                                          float* __restrict__ out, long HW, int C, long total4, int relu) {
+                                                          float* __restrict__ out, long HW, int C, int relu) {
     const int cg = C / 4;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
-        const int c = (int)(i % cg) * 4;
-        const long pix = i / cg;
-        const long b = pix / HW;
-        const float4 v = reinterpret_cast<const float4*>(x)[i];
-        const float4 mu = *reinterpret_cast<const float4*>(mean + b * C + c);
-        const float4 rs = *reinterpret_cast<const float4*>(rstd + b * C + c);
+    const int b = blockIdx.y;
+    const int c = (int)(threadIdx.x % cg) * 4;
+    const long per = HW * cg;                                   // float4 per image
+    const float4 mu = *reinterpret_cast<const float4*>(mean + (long)b * C + c);
+    const float4 rs = *reinterpret_cast<const float4*>(rstd + (long)b * C + c);
+    float4 m2 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = make_float4(1.f, 1.f, 1.f, 1.f);
+    if (rmean) {
+        m2 = *reinterpret_cast<const float4*>(rmean + (long)b * C + c);
+        s2 = *reinterpret_cast<const float4*>(rrstd + (long)b * C + c);
+    }
+    const float4* xi = reinterpret_cast<const float4*>(x) + (long)b * per;
+    const float4* ri = res ? reinterpret_cast<const float4*>(res) + (long)b * per : nullptr;
+    float4* oi = reinterpret_cast<float4*>(out) + (long)b * per;
+    const long step = (long)gridDim.x * blockDim.x;             // a multiple of cg: the channel quad stays put
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < per; i += step) {
+        const float4 v = xi[i];
         float4 y;
         y.x = (v.x - mu.x) * rs.x; y.y = (v.y - mu.y) * rs.y; y.z = (v.z - mu.z) * rs.z; y.w = (v.w - mu.w) * rs.w;
-        if (relu || res) {
+        if (relu || ri) {
             y.x = fmaxf(y.x, 0.f); y.y = fmaxf(y.y, 0.f); y.z = fmaxf(y.z, 0.f); y.w = fmaxf(y.w, 0.f);
         }
-        if (res) {
-            float4 r = reinterpret_cast<const float4*>(res)[i];
+        if (ri) {
+            float4 r = ri[i];
             if (rmean) {
-                const float4 m2 = *reinterpret_cast<const float4*>(rmean + b * C + c);
-                const float4 s2 = *reinterpret_cast<const float4*>(rrstd + b * C + c);
                 r.x = (r.x - m2.x) * s2.x; r.y = (r.y - m2.y) * s2.y; r.z = (r.z - m2.z) * s2.z; r.w = (r.w - m2.w) * s2.w;
             }
             y.x = fmaxf(r.x + y.x, 0.f); y.y = fmaxf(r.y + y.y, 0.f); y.z = fmaxf(r.z + y.z, 0.f); y.w = fmaxf(r.w + y.w, 0.f);
         }
-        reinterpret_cast<float4*>(out)[i] = y;
+        oi[i] = y;
     }
 }
 
@@ -323,11 +333,16 @@ int ofx_inorm_apply(const float* x, const float* mean, const float* rstd, const 
     OFX_REQUIRE(x && mean && rstd && out && B > 0 && HW > 0 && C > 0, OFX_EINVAL);
     OFX_REQUIRE(C % 4 == 0 && ofx_aligned16(x) && ofx_aligned16(out) && ofx_aligned16(mean) && ofx_aligned16(rstd), OFX_EALIGN);
     if (res_mean) OFX_REQUIRE(res && res_rstd, OFX_EINVAL);
-    const long total4 = (long)B * HW * (C / 4);
+    const int cg = C / 4;
+    OFX_REQUIRE(cg <= 256, OFX_EINVAL);
+    const int bs = (256 / cg) * cg;                              // block size: the largest multiple of C / 4 up to 256
+    const long per = HW * cg;
+    // enough workgroups to fill the chip whatever the batch; each thread then walks its image slice with a fixed channel quad
+    const long want = std::max<long>(1, (long)4096 / B);
+    const unsigned slices = (unsigned)std::min<long>((per + bs - 1) / bs, want);
     hipStream_t s = (hipStream_t)stream;
     OfxProfScope prof("inorm_apply", s);
-    hipLaunchKernelGGL(inorm_apply_kernel, dim3((unsigned)std::min<long>((total4 + 255) / 256, 16384)), dim3(256), 0, s, x,
-                       mean, rstd, res, res_mean, res_rstd, out, HW, C, total4, relu);
+    hipLaunchKernelGGL(inorm_apply_kernel, dim3(slices, (unsigned)B), dim3(bs), 0, s, x, mean, rstd, res, res_mean, res_rstd, out, HW, C, relu);
     return ofx_launch_status();
 }
 
