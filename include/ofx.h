@@ -139,7 +139,7 @@ int ofx_sd_handoff(const uint8_t* image_bgr, const uint8_t* reference_bgr, const
 /* GroupNorm(groups, C, eps, affine) of an NHWC fp32 tensor [B,HW,C] (ldm/modules/diffusionmodules/model.py:40-41,
  * `Normalize` = 32 groups, eps 1e-6), optionally followed by x * sigmoid(x) (`nonlinearity`, :35-37): the pair in front
  * of every convolution of the VAE encoder.  gamma / beta: [C] or NULL.  Statistics in f64.  out may alias x.
- * scratch: ofx_groupnorm_scratch_bytes(B, C) bytes, 16-byte aligned. */
+ * scratch: ofx_groupnorm_scratch_bytes(B, C) bytes, 16-byte aligned.  B <= 65535 (OFX_EINVAL beyond: slice the batch). */
 size_t ofx_groupnorm_scratch_bytes(int B, int C);
 int ofx_groupnorm(const float* x, const float* gamma, const float* beta, float* out, void* scratch, size_t scratch_bytes,
                   int B, long HW, int C, int groups, float eps, int silu, void* stream);
@@ -238,7 +238,8 @@ int ofx_split_conv_weight(const float* packed, long n_floats, float* out);
 int ofx_inorm_stats(const float* x, int ld, float* mean, float* rstd, float* scratch,
                     int B, long HW, int C, float eps, void* stream);
 /* out = relu?( (x-mean)*rstd ) ; with res: out = relu( r + relu((x-mean)*rstd) ) where
- * r = res (res_mean==NULL) or (res-res_mean)*res_rstd */
+ * r = res (res_mean==NULL) or (res-res_mean)*res_rstd.  C % 4 == 0 and C <= 1024 (a thread keeps one channel quad:
+ * OFX_EINVAL beyond); any B (batches over 65535 images are split into several launches). */
 int ofx_inorm_apply(const float* x, const float* mean, const float* rstd, const float* res,
                     const float* res_mean, const float* res_rstd, float* out, int B, long HW, int C,
                     int relu, void* stream);
@@ -300,6 +301,10 @@ size_t ofx_raft_workspace_bytes(const ofx_raft* r, int B, int H, int W);
 #define OFX_RAFT_ALT_CORR     8   /* on-the-fly local correlation instead of the volume (alt_cuda_corr) */
 #define OFX_RAFT_BF16X3      16   /* opt-in: split-bf16 matrix-core arithmetic for every convolution / the volume */
 #define OFX_RAFT_BF16X6      64   /* opt-in: three-piece split-bf16 arithmetic (OFX_PREC_BF16X6) for every convolution / the volume */
+#define OFX_RAFT_BN_BATCH   128   /* context-encoder BatchNorm on the statistics of the image itself (the reference's RAFT_2 as written:
+                                     a model never put in .eval(), one image per call) instead of the folded running statistics */
+#define OFX_RAFT_SEPARATE_STATS 256 /* diagnostic: instance-norm statistics by their own f64 pass over the stored tensor instead of
+                                     out of the convolution epilogues (fp32 partial sums per wave) */
 #define OFX_RAFT_SERIAL       32  /* keep every launch on the caller's stream (default: small batches run their
                                      independent chains on internal side streams, joined before returning) */
 

@@ -135,6 +135,13 @@ def init_state_dict(seed: int = 0) -> Dict[str, Tensor]:
     return sd
 
 
+def to_float64(sd: Dict[str, Tensor]) -> Dict[str, Tensor]:
+    """The same weights as float64 tensors: `raft_forward(to_float64(sd), image1.double(), image2.double())` evaluates the network
+    in double precision -- the yardstick that says how far the fp32 CPU oracle and the fp32 HIP path each sit from the exact
+    result of the same arithmetic (tests/test_gpu_raft.py, bench.py `verified`)."""
+    return {k: (v.double() if v.dtype.is_floating_point else v) for k, v in sd.items()}
+
+
 def strip_module_prefix(sd: Dict[str, Tensor]) -> Dict[str, Tensor]:
     """`raft-things.pth` is saved from `DataParallel(RAFT)` (ofgen_keyframe_inpaint.py:59-60)."""
     return {(k[7:] if k.startswith("module.") else k): v for k, v in sd.items()}
@@ -150,6 +157,12 @@ def _norm(sd, key: str, x: Tensor, kind: str) -> Tensor:
     if kind == "batch":
         return F.batch_norm(x, sd[key + ".running_mean"], sd[key + ".running_var"],
                             sd[key + ".weight"], sd[key + ".bias"], training=False, eps=1e-5)
+    if kind == "batch_train":
+        # nn.BatchNorm2d in TRAIN mode: the reference's RAFT_2 never calls .eval() (ofgen_keyframe_inpaint.py:47-60), so
+        # raft.py:55's BatchNorm layers normalise with the statistics of the call's batch -- always ONE image there.  A batch
+        # here stands for as many reference calls: every image is normalised by itself.
+        return torch.cat([F.batch_norm(x[i:i + 1], None, None, sd[key + ".weight"], sd[key + ".bias"], training=True, eps=1e-5)
+                          for i in range(x.shape[0])], 0)
     raise ValueError(kind)
 
 
@@ -351,10 +364,10 @@ def update_block(sd, net: Tensor, inp: Tensor, corr: Tensor, flow: Tensor,
 # --------------------------------------------------------------------------------------
 # convex upsample, grids, padding
 # --------------------------------------------------------------------------------------
-def coords_grid(b: int, h: int, w: int) -> Tensor:
+def coords_grid(b: int, h: int, w: int, dtype=torch.float32) -> Tensor:
     """utils.py:74-77: channel 0 = x (column), channel 1 = y (row)."""
-    ys, xs = torch.meshgrid(torch.arange(h, dtype=torch.float32),
-                            torch.arange(w, dtype=torch.float32), indexing="ij")
+    ys, xs = torch.meshgrid(torch.arange(h, dtype=dtype),
+                            torch.arange(w, dtype=dtype), indexing="ij")
     return torch.stack([xs, ys], 0)[None].repeat(b, 1, 1, 1)
 
 
@@ -384,23 +397,25 @@ def pad_to_8(img: Tensor) -> Tuple[Tensor, Tuple[int, int, int, int]]:
 # --------------------------------------------------------------------------------------
 @torch.no_grad()
 def raft_forward(sd: Dict[str, Tensor], image1: Tensor, image2: Tensor, iters: int = 20,
-                 alternate_corr: bool = False, trace: Optional[dict] = None
+                 alternate_corr: bool = False, trace: Optional[dict] = None, cnet_norm: str = "eval"
                  ) -> Tuple[Tensor, Tensor]:
     """RAFT.forward(test_mode=True), raft.py:86-144.  image1/2: [B,3,H,W] float in [0,255] (RGB),
     H and W multiples of 8.  Returns (flow_low [B,2,H/8,W/8], flow_up [B,2,H,W]).
-    `trace`, if a dict, receives intermediate tensors for stage-level parity tests."""
+    `trace`, if a dict, receives intermediate tensors for stage-level parity tests.
+    cnet_norm: 'eval' = BatchNorm with running statistics (model.eval()); 'batch' = BatchNorm in train mode, one image
+    per call (RAFT_2 as the reference wrote it, see `_norm`)."""
     i1 = 2 * (image1 / 255.0) - 1.0
     i2 = 2 * (image2 / 255.0) - 1.0
     b = i1.shape[0]
     fm = encoder(sd, "fnet", torch.cat([i1, i2], 0), "instance")
     fmap1, fmap2 = fm[:b], fm[b:]
-    cn = encoder(sd, "cnet", i1, "batch")
+    cn = encoder(sd, "cnet", i1, {"eval": "batch", "batch": "batch_train"}[cnet_norm])
     net = torch.tanh(cn[:, :HDIM])
     inp = torch.relu(cn[:, HDIM:HDIM + CDIM])
     _, _, h, w = fmap1.shape
     pyr = None if alternate_corr else corr_pyramid(fmap1, fmap2)
-    coords0 = coords_grid(b, h, w)
-    coords1 = coords_grid(b, h, w)
+    coords0 = coords_grid(b, h, w, fmap1.dtype)
+    coords1 = coords_grid(b, h, w, fmap1.dtype)
     if trace is not None:
         trace.update(fmap1=fmap1, fmap2=fmap2, net0=net, inp=inp, pyramid=pyr)
     mask = None
@@ -416,6 +431,8 @@ def raft_forward(sd: Dict[str, Tensor], image1: Tensor, image2: Tensor, iters: i
         coords1 = coords1 + delta
         if trace is not None and it == 0:
             trace.update(corr_it0=corr, net_it0=net, delta_it0=delta)
+        if trace is not None and (it + 1) in trace.get("keep_iters", ()):
+            trace.setdefault("flow_low_at", {})[it + 1] = coords1 - coords0    # 1/8-resolution flow after it + 1 iterations
     flow_low = coords1 - coords0
     flow_up = upsample_flow(flow_low, mask)
     if trace is not None:
@@ -424,7 +441,7 @@ def raft_forward(sd: Dict[str, Tensor], image1: Tensor, image2: Tensor, iters: i
 
 
 @torch.no_grad()
-def raft2_calc(sd, img1_bgr, img2_bgr, iters: int = 20):
+def raft2_calc(sd, img1_bgr, img2_bgr, iters: int = 20, cnet_norm: str = "batch"):
     """`RAFT_2.calc` (ofgen_keyframe_inpaint.py:62-71): BGR uint8 HxWx3 numpy in -> flow
     f32[H',W',2] numpy out, H',W' = padded size (the reference does not un-pad, :70)."""
     import numpy as np
@@ -432,7 +449,7 @@ def raft2_calc(sd, img1_bgr, img2_bgr, iters: int = 20):
     c = torch.from_numpy(np.ascontiguousarray(img2_bgr[:, :, ::-1])).permute(2, 0, 1).float()[None]
     a, _ = pad_to_8(a)
     c, _ = pad_to_8(c)
-    _, up = raft_forward(sd, a, c, iters=iters)
+    _, up = raft_forward(sd, a, c, iters=iters, cnet_norm=cnet_norm)
     return up[0].permute(1, 2, 0).contiguous().numpy()
 
 

@@ -6,8 +6,8 @@ The reference cannot run `ldm/` without xformers: both attention modules call
 built from the flow-guided neighbourhood (:283-311, :392-423).  `memory_efficient_attention` below has that signature
 and those semantics -- softmax(q k^T / sqrt(dim_head) + attn_bias) v -- and runs on the HIP kernels of libofx.so
 (`ofx_attention_f32`: both products on the fp32 matrix cores, exact fp32 softmax; the UNet's head sizes 40 / 64 / 80 /
-128 / 160 take the fused online-softmax kernel of csrc/attn_flash.hip, which keeps the scores on the CU).  The top-level `xformers` package of
-this repository re-exports it, so `import xformers.ops` in the reference resolves here unchanged.
+128 / 160 take the fused online-softmax kernel of csrc/attn_flash.hip, which keeps the scores on the CU).  The `xformers` package under `shims/`
+re-exports it: with `<repo>/shims` on `sys.path`, `import xformers.ops` in the reference resolves here unchanged.
 
 Half / bfloat16 inputs are computed in fp32 and cast back (xformers computes them at reduced precision; fp32 is the
 stricter arithmetic).  A 4-D bias [batch, heads, Nq, Nk] is accepted like xformers'.
@@ -25,6 +25,9 @@ def memory_efficient_attention(query: torch.Tensor, key: torch.Tensor, value: to
                                p: float = 0.0, scale: Optional[float] = None, op=None) -> torch.Tensor:
     if p != 0.0:
         raise NotImplementedError("attention dropout is a training feature; the reference's inference calls use p = 0")
+    if attn_bias is not None and not torch.is_tensor(attn_bias):
+        # xformers' AttentionBias objects (LowerTriangularMask, BlockDiagonalMask ...): the reference never passes one
+        raise TypeError(f"attn_bias must be a tensor (additive bias); {type(attn_bias).__name__} objects are not supported")
     if not query.is_cuda:
         raise RuntimeError("memory_efficient_attention needs CUDA tensors (no CPU fallback)")
     dt = query.dtype

@@ -70,8 +70,25 @@ __global__ __launch_bounds__(256) void inorm_partial_kernel(const float* __restr
 
 // one workgroup per (image, 16 channels): thread t sums the slices t / 16, t / 16 + 16, ... of channel t % 16, then the
 // 16 partial sums of a channel are added through LDS in a fixed order (deterministic)
+// Optional affine (gamma, beta: the context encoder's BatchNorm evaluated with per-image statistics, see raft_engine.cpp): folded into
+// the pair the consumers already apply as (x - mean) * rstd:   (x - mu) * rs * g + b  =  (x - (mu - b / (rs g))) * (rs g).
+__device__ __forceinline__ void inorm_store(float* mean, float* rstd, int i, int c, double mu, double var, float eps,
+                                            const float* gamma, const float* beta) {
+    if (var < 0) var = 0;
+    double rs = 1.0 / sqrt(var + (double)eps);
+    if (gamma) {
+        double a = rs * (double)gamma[c];
+        if (fabs(a) < 1e-30) a = 1e-30;       // gamma == 0: the output is beta whatever x is
+        mu -= (double)beta[c] / a;
+        rs = a;
+    }
+    mean[i] = (float)mu;
+    rstd[i] = (float)rs;
+}
+
 __global__ __launch_bounds__(256) void inorm_finalize_kernel(const double* __restrict__ part, float* __restrict__ mean,
-                                                             float* __restrict__ rstd, long HW, int C, float eps, int kSlices) {
+                                                             float* __restrict__ rstd, long HW, int C, float eps, int kSlices,
+                                                             const float* __restrict__ gamma, const float* __restrict__ beta) {
     __shared__ double red[256 * 2];
     const int b = blockIdx.y;
     const int c = blockIdx.x * 16 + (threadIdx.x & 15), gsl = threadIdx.x >> 4;
@@ -91,12 +108,8 @@ __global__ __launch_bounds__(256) void inorm_finalize_kernel(const double* __res
         s += red[(g2 * 16 + threadIdx.x) * 2];
         q += red[(g2 * 16 + threadIdx.x) * 2 + 1];
     }
-    const int i = b * C + c;
     const double mu = s / (double)HW;
-    double var = q / (double)HW - mu * mu;
-    if (var < 0) var = 0;
-    mean[i] = (float)mu;
-    rstd[i] = (float)(1.0 / sqrt(var + (double)eps));
+    inorm_store(mean, rstd, b * C + c, c, mu, q / (double)HW - mu * mu, eps, gamma, beta);
 }
 
 // The same finalisation for statistics that come out of the convolution epilogue (conv.hip, ofx_conv2d_stats): `part` holds, per
@@ -105,7 +118,8 @@ __global__ __launch_bounds__(256) void inorm_finalize_kernel(const double* __res
 // only a few images: the work has to spread over rows), then the 64 partial sums of a channel are added through LDS in a fixed
 // order.
 __global__ __launch_bounds__(256) void inorm_finalize_part_kernel(const float* __restrict__ part, float* __restrict__ mean,
-                                                                  float* __restrict__ rstd, long HW, int C, float eps, int rows) {
+                                                                  float* __restrict__ rstd, long HW, int C, float eps, int rows,
+                                                                  const float* __restrict__ gamma, const float* __restrict__ beta) {
     __shared__ double red[256 * 2];
     const int b = blockIdx.y;
     const int c = blockIdx.x * 4 + (threadIdx.x & 3), g = threadIdx.x >> 2;
@@ -125,12 +139,8 @@ __global__ __launch_bounds__(256) void inorm_finalize_part_kernel(const float* _
         s += red[(g2 * 4 + threadIdx.x) * 2];
         q += red[(g2 * 4 + threadIdx.x) * 2 + 1];
     }
-    const int i = b * C + c;
     const double mu = s / (double)HW;
-    double var = q / (double)HW - mu * mu;
-    if (var < 0) var = 0;
-    mean[i] = (float)mu;
-    rstd[i] = (float)(1.0 / sqrt(var + (double)eps));
+    inorm_store(mean, rstd, b * C + c, c, mu, q / (double)HW - mu * mu, eps, gamma, beta);
 }
 
 // grid (slices, B), block = a multiple of C / 4 threads: a thread keeps one channel quad of one image for its whole loop, so its
@@ -311,6 +321,14 @@ int ofx_preprocess_u8(const uint8_t* img, float* out, long npix, int bgr, void* 
 
 int ofx_inorm_stats(const float* x, int ld, float* mean, float* rstd, float* scratch, int B, long HW, int C, float eps,
                     void* stream) {
+    return ofx_inorm_stats_affine(x, ld, mean, rstd, scratch, B, HW, C, eps, nullptr, nullptr, (hipStream_t)stream);
+}
+
+}  // extern "C"
+
+int ofx_inorm_stats_affine(const float* x, int ld, float* mean, float* rstd, float* scratch, int B, long HW, int C, float eps,
+                           const float* gamma, const float* beta, hipStream_t stream) {
+    OFX_REQUIRE(!gamma == !beta, OFX_EINVAL);
     OFX_REQUIRE(x && mean && rstd && scratch && B > 0 && HW > 0 && C > 0, OFX_EINVAL);
     OFX_REQUIRE(C % 4 == 0 && C <= 256 && ld % 4 == 0 && ld >= C && ofx_aligned16(x), OFX_EALIGN);
     OFX_REQUIRE((((uintptr_t)scratch) & 7u) == 0, OFX_EALIGN);
@@ -324,9 +342,11 @@ int ofx_inorm_stats(const float* x, int ld, float* mean, float* rstd, float* scr
     int st = ofx_launch_status();
     if (st) return st;
     OfxProfScope prof("inorm_finalize", s);
-    hipLaunchKernelGGL(inorm_finalize_kernel, dim3(ofx_cdiv(C, 16), B), dim3(256), 0, s, part, mean, rstd, HW, C, eps, slices);
+    hipLaunchKernelGGL(inorm_finalize_kernel, dim3(ofx_cdiv(C, 16), B), dim3(256), 0, s, part, mean, rstd, HW, C, eps, slices, gamma, beta);
     return ofx_launch_status();
 }
+
+extern "C" {
 
 int ofx_inorm_apply(const float* x, const float* mean, const float* rstd, const float* res, const float* res_mean,
                     const float* res_rstd, float* out, int B, long HW, int C, int relu, void* stream) {
@@ -342,7 +362,13 @@ int ofx_inorm_apply(const float* x, const float* mean, const float* rstd, const 
     const unsigned slices = (unsigned)std::min<long>((per + bs - 1) / bs, want);
     hipStream_t s = (hipStream_t)stream;
     OfxProfScope prof("inorm_apply", s);
-    hipLaunchKernelGGL(inorm_apply_kernel, dim3(slices, (unsigned)B), dim3(bs), 0, s, x, mean, rstd, res, res_mean, res_rstd, out, HW, C, relu);
+    // the image index rides on gridDim.y (<= 65535): larger batches go in several launches
+    for (long b0 = 0; b0 < B; b0 += 65535) {
+        const unsigned nb = (unsigned)std::min<long>(65535, B - b0);
+        const long eo = b0 * HW * C, so = b0 * C;
+        hipLaunchKernelGGL(inorm_apply_kernel, dim3(slices, nb), dim3(bs), 0, s, x + eo, mean + so, rstd + so, res ? res + eo : nullptr,
+                           res_mean ? res_mean + so : nullptr, res_rstd ? res_rstd + so : nullptr, out + eo, HW, C, relu);
+    }
     return ofx_launch_status();
 }
 
@@ -359,10 +385,11 @@ int ofx_upsample_flow(const float* coords1, const float* mask, float* flow_up, i
 
 }  // extern "C"
 
-int ofx_inorm_finalize_part(const float* part, float* mean, float* rstd, int B, int rows, long HW, int C, float eps, hipStream_t s) {
-    OFX_REQUIRE(part && mean && rstd && B > 0 && rows > 0 && HW > 0 && C > 0, OFX_EINVAL);
+int ofx_inorm_finalize_part(const float* part, float* mean, float* rstd, int B, int rows, long HW, int C, float eps, hipStream_t s,
+                            const float* gamma, const float* beta) {
+    OFX_REQUIRE(part && mean && rstd && B > 0 && rows > 0 && HW > 0 && C > 0 && !gamma == !beta, OFX_EINVAL);
     OfxProfScope prof("inorm_finalize", s);
-    hipLaunchKernelGGL(inorm_finalize_part_kernel, dim3(ofx_cdiv(C, 4), B), dim3(256), 0, s, part, mean, rstd, HW, C, eps, rows);
+    hipLaunchKernelGGL(inorm_finalize_part_kernel, dim3(ofx_cdiv(C, 4), B), dim3(256), 0, s, part, mean, rstd, HW, C, eps, rows, gamma, beta);
     return ofx_launch_status();
 }
 

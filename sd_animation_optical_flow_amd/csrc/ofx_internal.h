@@ -45,7 +45,11 @@ int ofx_conv2d_volpool(const ofx_conv_desc* d, float alpha, float* pool_out, lon
 // conv.hip / net_misc.hip: instance-norm statistics out of the convolution epilogue (rows_per_image = 0: not produced, use
 // ofx_inorm_stats) and their per-image reduction
 int ofx_conv2d_stats(const ofx_conv_desc* d, float* part, size_t part_floats, int* rows_per_image, void* stream);
-int ofx_inorm_finalize_part(const float* part, float* mean, float* rstd, int B, int rows, long HW, int C, float eps, hipStream_t s);
+// gamma / beta (both or neither): an affine folded into the (mean, rstd) pair, (x - mean') * rstd' = (x - mu) * rs * gamma + beta
+int ofx_inorm_finalize_part(const float* part, float* mean, float* rstd, int B, int rows, long HW, int C, float eps, hipStream_t s,
+                            const float* gamma = nullptr, const float* beta = nullptr);
+int ofx_inorm_stats_affine(const float* x, int ld, float* mean, float* rstd, float* scratch, int B, long HW, int C, float eps,
+                           const float* gamma, const float* beta, hipStream_t stream);
 
 // attn_flash.hip: fused attention for the UNet's head sizes (no workspace)
 bool ofx_attention_flash_ok(int D);

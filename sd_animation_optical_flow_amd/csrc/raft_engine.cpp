@@ -97,6 +97,8 @@ struct Carver {
 
 struct ofx_raft {
     std::map<std::string, ConvW> convs;
+    // gamma / beta of the context encoder's BatchNorm layers for the batch-statistics mode (OFX_RAFT_BN_BATCH), by norm name
+    std::map<std::string, std::pair<float*, float*>> affine;
     std::vector<void*> allocs;
     std::map<std::string, std::pair<void*, size_t>> bufs;
     // side streams for the small-batch schedule (see overlap_pays): independent chains of a forward run
@@ -215,25 +217,47 @@ int add_conv(ofx_raft* r, const std::map<std::string, HostTensor>& sd, const std
     return 0;
 }
 
-int build_encoder(ofx_raft* r, const std::map<std::string, HostTensor>& sd, const std::string& enc, bool bn) {
-    auto B = [&](const std::string& n) { return bn ? enc + "." + n : std::string(); };
-    int st = add_conv(r, sd, enc + ".conv1", enc + ".conv1", 4, B("norm1"), 1.f);
+// `as`: name the packed layers are stored under.  "cnetb" = the context encoder's convolutions WITHOUT the folded running
+// statistics, plus gamma / beta of every BatchNorm: the layers of the batch-statistics mode (see ofx_raft_forward).
+int build_encoder(ofx_raft* r, const std::map<std::string, HostTensor>& sd, const std::string& enc, bool bn,
+                  const std::string& as_ = std::string()) {
+    const std::string as = as_.empty() ? enc : as_;
+    const bool affine = !as_.empty();
+    auto B = [&](const std::string& n) { return bn && !affine ? enc + "." + n : std::string(); };
+    auto A = [&](const std::string& n) -> int {   // upload gamma / beta of norm layer `n`
+        if (!affine) return 0;
+        const HostTensor* g = find(sd, enc + "." + n + ".weight");
+        const HostTensor* be = find(sd, enc + "." + n + ".bias");
+        if (!g || !be || g->numel() != be->numel() || g->numel() % 4) return OFX_EKEY;
+        std::vector<float> hg(g->data, g->data + g->numel()), hb(be->data, be->data + be->numel());
+        float *dg = nullptr, *db = nullptr;
+        int st = upload(r, hg, &dg);
+        if (!st) st = upload(r, hb, &db);
+        r->affine[as + "." + n] = std::make_pair(dg, db);
+        return st;
+    };
+    int st = add_conv(r, sd, enc + ".conv1", as + ".conv1", 4, B("norm1"), 1.f);
+    if (!st) st = A("norm1");
     if (st) return st;
     for (int li = 1; li <= 3; ++li) {
         for (int bi = 0; bi < 2; ++bi) {
             const std::string p = enc + ".layer" + std::to_string(li) + "." + std::to_string(bi);
+            const std::string pa = as + ".layer" + std::to_string(li) + "." + std::to_string(bi);
             const std::string pb = "layer" + std::to_string(li) + "." + std::to_string(bi);
-            st = add_conv(r, sd, p + ".conv1", p + ".conv1", 0, B(pb + ".norm1"), 1.f);
+            st = add_conv(r, sd, p + ".conv1", pa + ".conv1", 0, B(pb + ".norm1"), 1.f);
+            if (!st) st = A(pb + ".norm1");
             if (st) return st;
-            st = add_conv(r, sd, p + ".conv2", p + ".conv2", 0, B(pb + ".norm2"), 1.f);
+            st = add_conv(r, sd, p + ".conv2", pa + ".conv2", 0, B(pb + ".norm2"), 1.f);
+            if (!st) st = A(pb + ".norm2");
             if (st) return st;
             if (li > 1 && bi == 0) {
-                st = add_conv(r, sd, p + ".downsample.0", p + ".down", 0, B(pb + ".norm3"), 1.f);
+                st = add_conv(r, sd, p + ".downsample.0", pa + ".down", 0, B(pb + ".norm3"), 1.f);
+                if (!st) st = A(pb + ".norm3");
                 if (st) return st;
             }
         }
     }
-    return add_conv(r, sd, enc + ".conv2", enc + ".conv2", 0, "", 1.f);
+    return add_conv(r, sd, enc + ".conv2", as + ".conv2", 0, "", 1.f);
 }
 
 int build_gru(ofx_raft* r, const std::map<std::string, HostTensor>& sd, const std::string& tag) {
@@ -358,7 +382,7 @@ struct EncBufs {
 // --------------------------------------------------------------------------------------------
 static int run_encoder(ofx_raft* r, const std::string& enc, bool bn, const uint8_t* imgs, int n, int H, int W,
                        int bgr, const EncBufs& eb, float* out, int out_ld, bool split_tanh_relu, int relu_off, hipStream_t s,
-                       int precision = OFX_PREC_FP32) {
+                       int precision = OFX_PREC_FP32, bool separate_stats = false) {
     // `out`: [n*h*w][out_ld]; fnet writes 256 channels; cnet writes tanh(0:128) | relu(128:256)
     Launcher L{s};
     L.precision = precision;
@@ -371,16 +395,20 @@ static int run_encoder(ofx_raft* r, const std::string& enc, bool bn, const uint8
     auto C = [&](const std::string& k) -> const ConvW& { return r->convs[enc + "." + k]; };
     int st = ofx_preprocess_u8(imgs, eb.x0, (long)n * H * W, bgr, s);
     if (st) return st;
-    // statistics of the tensor the conv() just before has written: from its epilogue's partial sums when it produced them
-    auto stats = [&](const float* x, long HW, int ch, float* mean, float* rstd) {
+    // statistics of the tensor the conv() just before has written: from its epilogue's partial sums when it produced them.
+    // `norm`: the layer's name -- for "cnetb" (BatchNorm on per-image statistics) its gamma / beta are folded into (mean, rstd)
+    auto stats = [&](const float* x, long HW, int ch, float* mean, float* rstd, const std::string& norm) {
         if (L.st) return;
-        if (L.stats_rows > 0) L.st = ofx_inorm_finalize_part(eb.spart, mean, rstd, n, L.stats_rows, HW, ch, 1e-5f, s);
-        else L.st = ofx_inorm_stats(x, ch, mean, rstd, eb.scratch, n, HW, ch, 1e-5f, s);
+        const float *gamma = nullptr, *beta = nullptr;
+        auto af = r->affine.find(enc + "." + norm);
+        if (af != r->affine.end()) { gamma = af->second.first; beta = af->second.second; }
+        if (L.stats_rows > 0) L.st = ofx_inorm_finalize_part(eb.spart, mean, rstd, n, L.stats_rows, HW, ch, 1e-5f, s, gamma, beta);
+        else L.st = ofx_inorm_stats_affine(x, ch, mean, rstd, eb.scratch, n, HW, ch, 1e-5f, gamma, beta, s);
         L.stats_rows = 0;
     };
     static const bool no_epi_stats = getenv("OFX_NO_EPI_STATS") != nullptr;     // diagnostic: always the separate statistics pass
     auto want_stats = [&]() {
-        if (no_epi_stats) return;
+        if (no_epi_stats || separate_stats) return;
         L.stats_part = eb.spart;
         L.stats_floats = eb.spart_floats;
     };
@@ -389,7 +417,7 @@ static int run_encoder(ofx_raft* r, const std::string& enc, bool bn, const uint8
     if (!bn) {
         want_stats();
         L.conv(C("conv1"), eb.x0, 4, 4, nullptr, 0, 0, eb.R1, 64, n, H, W, 2, OFX_ACT_NONE);
-        stats(eb.R1, (long)H2 * W2, 64, m1, s1);
+        stats(eb.R1, (long)H2 * W2, 64, m1, s1, "norm1");
         if (!L.st) L.st = ofx_inorm_apply(eb.R1, m1, s1, nullptr, nullptr, nullptr, X, n, (long)H2 * W2, 64, 1, s);
     } else {
         L.conv(C("conv1"), eb.x0, 4, 4, nullptr, 0, 0, X, 64, n, H, W, 2, OFX_ACT_RELU);
@@ -405,16 +433,16 @@ static int run_encoder(ofx_raft* r, const std::string& enc, bool bn, const uint8
             if (!bn) {
                 want_stats();
                 L.conv(C(p + ".conv1"), X, cin, cin, nullptr, 0, 0, eb.R1, dim, n, hin, win, stride, OFX_ACT_NONE);
-                stats(eb.R1, (long)ho * wo, dim, m1, s1);
+                stats(eb.R1, (long)ho * wo, dim, m1, s1, p + ".norm1");
                 // norm1 + ReLU fused into conv2's operand load
                 want_stats();
                 L.conv(C(p + ".conv2"), eb.R1, dim, dim, nullptr, 0, 0, eb.R2, dim, n, ho, wo, 1, OFX_ACT_NONE,
                        OFX_EPI_PLAIN, nullptr, 0, m1, s1);
-                stats(eb.R2, (long)ho * wo, dim, m2, s2);
+                stats(eb.R2, (long)ho * wo, dim, m2, s2, p + ".norm2");
                 if (stride == 2) {
                     want_stats();
                     L.conv(C(p + ".down"), X, cin, cin, nullptr, 0, 0, eb.R3, dim, n, hin, win, 2, OFX_ACT_NONE);
-                    stats(eb.R3, (long)ho * wo, dim, m3, s3);
+                    stats(eb.R3, (long)ho * wo, dim, m3, s3, p + ".norm3");
                     if (!L.st) L.st = ofx_inorm_apply(eb.R2, m2, s2, eb.R3, m3, s3, Y, n, (long)ho * wo, dim, 1, s);
                 } else {
                     if (!L.st) L.st = ofx_inorm_apply(eb.R2, m2, s2, X, nullptr, nullptr, Y, n, (long)ho * wo, dim, 1, s);
@@ -628,6 +656,7 @@ int ofx_raft_create(const ofx_tensor* tensors, int n, ofx_raft** out) {
     ofx_raft* r = new ofx_raft();
     int st = build_encoder(r, sd, "fnet", false);
     if (!st) st = build_encoder(r, sd, "cnet", true);
+    if (!st) st = build_encoder(r, sd, "cnet", true, "cnetb");
     const char* ub = "update_block.";
     if (!st) st = add_conv(r, sd, std::string(ub) + "encoder.convc1", "convc1", 0, "", 1.f);
     if (!st) st = add_conv(r, sd, std::string(ub) + "encoder.convc2", "convc2", 0, "", 1.f);
@@ -692,6 +721,14 @@ int ofx_raft_forward(ofx_raft* r, const uint8_t* image1, const uint8_t* image2, 
     const bool sh1 = flags & OFX_RAFT_SHARED_IMG1, sh2 = flags & OFX_RAFT_SHARED_IMG2;
     const bool alt = flags & OFX_RAFT_ALT_CORR;
     const long img_bytes = (long)H * W * 3;
+    // Context-encoder BatchNorm.  Default: the running statistics, folded into the convolutions (a model in .eval(), as PDCNet's
+    // own code and canonical RAFT inference run it).  OFX_RAFT_BN_BATCH: the statistics of the image itself -- what
+    // `RAFT_2` computes AS WRITTEN: the reference never calls .eval() (ofgen_keyframe_inpaint.py:47-60), so its
+    // BatchNorm2d layers (RAFT/core/raft.py:55, extractor.py:118-192) normalise with the statistics of the call's batch,
+    // and every call is one image.  Each image of a batch is normalised by itself here (= B reference calls).
+    const bool bnb = flags & OFX_RAFT_BN_BATCH;
+    const bool sepst = flags & OFX_RAFT_SEPARATE_STATS;
+    const char* cnet = bnb ? "cnetb" : "cnet";
 
     // ---- encoders (instance norm => per-image statistics, so chunking is exact).  Three independent chains:
     // fnet(image1) on the caller's stream, fnet(image2) and cnet(image1) on the side streams when the batch is
@@ -706,24 +743,24 @@ int ofx_raft_forward(ofx_raft* r, const uint8_t* image1, const uint8_t* image2, 
     for (int i0 = 0; i0 < n1 && !st; i0 += ech) {
         const int n = std::min(ech, n1 - i0);
         st = run_encoder(r, "fnet", false, image1 + i0 * img_bytes, n, H, W, bgr, ws.eb[0], ws.fmap1 + (long)i0 * N * FD, FD,
-                         false, 0, s, prec);
+                         false, 0, s, prec, sepst);
     }
     for (int i0 = 0; i0 < n2 && !st; i0 += ech) {
         const int n = std::min(ech, n2 - i0);
         st = run_encoder(r, "fnet", false, image2 + i0 * img_bytes, n, H, W, bgr, ws.eb[1], ws.fmap2 + (long)i0 * N * FD, FD,
-                         false, 0, S.get(0), prec);
+                         false, 0, S.get(0), prec, sepst);
     }
     // context encoder on image1 -> hx[:, 0:128] = tanh (net), hx[:, 256:384] = relu (inp)
     if (sh1) {
-        if (!st) st = run_encoder(r, "cnet", true, image1, 1, H, W, bgr, ws.eb[2], ws.hx, HX_LD, true, INP_OFF, S.get(1), prec);
+        if (!st) st = run_encoder(r, cnet, !bnb, image1, 1, H, W, bgr, ws.eb[2], ws.hx, HX_LD, true, INP_OFF, S.get(1), prec, sepst);
         for (int k = 1; k < B && !st; ++k)   // one shared image1: replicate its context rows
             OFX_HIP_CHECK(hipMemcpyAsync(ws.hx + (long)k * N * HX_LD, ws.hx, (size_t)N * HX_LD * sizeof(float),
                                          hipMemcpyDeviceToDevice, S.get(1)));
     } else {
         for (int i0 = 0; i0 < B && !st; i0 += ech) {
             const int n = std::min(ech, B - i0);
-            st = run_encoder(r, "cnet", true, image1 + i0 * img_bytes, n, H, W, bgr, ws.eb[2], ws.hx + (long)i0 * N * HX_LD,
-                             HX_LD, true, INP_OFF, S.get(1), prec);
+            st = run_encoder(r, cnet, !bnb, image1 + i0 * img_bytes, n, H, W, bgr, ws.eb[2], ws.hx + (long)i0 * N * HX_LD,
+                             HX_LD, true, INP_OFF, S.get(1), prec, sepst);
         }
     }
     if (!st) st = S.join(0);
@@ -806,6 +843,14 @@ int ofx_raft_forward_pairs(ofx_raft* r, const uint8_t* images, int n_images, con
     const int bgr = (flags & OFX_RAFT_BGR) ? 1 : 0;
     const int prec = (flags & OFX_RAFT_BF16X6) ? OFX_PREC_BF16X6 : (flags & OFX_RAFT_BF16X3) ? OFX_PREC_BF16X3 : OFX_PREC_FP32;
     const long img_bytes = (long)H * W * 3;
+    // Context-encoder BatchNorm.  Default: the running statistics, folded into the convolutions (a model in .eval(), as PDCNet's
+    // own code and canonical RAFT inference run it).  OFX_RAFT_BN_BATCH: the statistics of the image itself -- what
+    // `RAFT_2` computes AS WRITTEN: the reference never calls .eval() (ofgen_keyframe_inpaint.py:47-60), so its
+    // BatchNorm2d layers (RAFT/core/raft.py:55, extractor.py:118-192) normalise with the statistics of the call's batch,
+    // and every call is one image.  Each image of a batch is normalised by itself here (= B reference calls).
+    const bool bnb = flags & OFX_RAFT_BN_BATCH;
+    const bool sepst = flags & OFX_RAFT_SEPARATE_STATS;
+    const char* cnet = bnb ? "cnetb" : "cnet";
     int st = 0;
     // every image is encoded ONCE (feature + context), however many pairs it takes part in: a 15-frame
     // KeyframeConv window has 210 ordered pairs but only 15 images (ofgen_keyframe_inpaint.py:627-668)
@@ -815,10 +860,10 @@ int ofx_raft_forward_pairs(ofx_raft* r, const uint8_t* images, int n_images, con
     for (int i0 = 0; i0 < n_images && !st; i0 += enc_chunk(H, W)) {
         const int n = std::min(enc_chunk(H, W), n_images - i0);
         st = run_encoder(r, "fnet", false, images + i0 * img_bytes, n, H, W, bgr, ws.eb[0], ws.fmap1 + (long)i0 * N * FD, FD,
-                         false, 0, s, prec);
+                         false, 0, s, prec, sepst);
         if (!st)
-            st = run_encoder(r, "cnet", true, images + i0 * img_bytes, n, H, W, bgr, ws.eb[2], ws.ctx + (long)i0 * N * (HD + CD),
-                             HD + CD, true, HD, S.get(1), prec);
+            st = run_encoder(r, cnet, !bnb, images + i0 * img_bytes, n, H, W, bgr, ws.eb[2], ws.ctx + (long)i0 * N * (HD + CD),
+                             HD + CD, true, HD, S.get(1), prec, sepst);
     }
     if (!st) st = S.join(1);
     if (st) return st;

@@ -216,7 +216,7 @@ size_t ofx_groupnorm_scratch_bytes(int B, int C) { return (size_t)B * gn_slices(
 
 int ofx_groupnorm(const float* x, const float* gamma, const float* beta, float* out, void* scratch, size_t scratch_bytes, int B,
                   long HW, int C, int groups, float eps, int silu, void* stream) {
-    OFX_REQUIRE(x && out && scratch && B > 0 && HW > 0 && C > 0 && groups > 0 && C % groups == 0, OFX_EINVAL);
+    OFX_REQUIRE(x && out && scratch && B > 0 && B <= 65535 && HW > 0 && C > 0 && groups > 0 && C % groups == 0, OFX_EINVAL);
     OFX_REQUIRE(C % 4 == 0 && ofx_aligned16(x) && ofx_aligned16(out) && ofx_aligned16(scratch), OFX_EALIGN);
     OFX_REQUIRE(scratch_bytes >= ofx_groupnorm_scratch_bytes(B, C), OFX_ENOMEM);
     hipStream_t s = (hipStream_t)stream;

@@ -49,15 +49,18 @@ class namespace:
 class RAFT_2:
     """ofgen_keyframe_inpaint.py:47-71.  `model` = checkpoint path / state_dict / 'random:<seed>'.
 
-    One deliberate difference: the reference never calls `.eval()` on its RAFT (:47-60), so as written its context
-    encoder's BatchNorm uses per-call batch statistics; the engine folds the running statistics (canonical RAFT
-    inference, and what the golden vectors pin) -- see DESIGN.md section 2."""
+    `cnet_norm='batch'` (the default here) is the reference AS WRITTEN: `RAFT_2.__init__` (:47-60) never calls `.eval()`,
+    so the context encoder's BatchNorm2d layers (RAFT/core/raft.py:55) normalise each call's single image with its own
+    statistics (then gamma / beta) and the checkpoint's running statistics are never used.  `cnet_norm='eval'` is
+    canonical RAFT inference (running statistics) for callers who want that instead.  Pinned by
+    tests/golden/raft_ref_trainbn_128x160.npz (the reference module left in train mode) -- DESIGN.md section 2."""
 
-    def __init__(self, model="../RAFT/models/raft-things.pth", device="cuda", iters: int = 20, alternate_corr: bool = False):
+    def __init__(self, model="../RAFT/models/raft-things.pth", device="cuda", iters: int = 20, alternate_corr: bool = False,
+                 cnet_norm: str = "batch"):
         self.device = torch.device(device)
         self.iters = iters
         self.alternate_corr = alternate_corr
-        self.model = RaftEngine(load_checkpoint(model), self.device)
+        self.model = RaftEngine(load_checkpoint(model), self.device, cnet_norm=cnet_norm)
 
     @torch.no_grad()
     def calc(self, img1: np.ndarray, img2: np.ndarray) -> np.ndarray:
@@ -429,4 +432,9 @@ def keyframe_conv(pdcnet: PDCNetAux, workspace: str, video, frames, kernel_size:
     return VideoFrameIndices(winners)
 
 
-KeyframeConv = keyframe_conv          # the reference's spelling
+def KeyframeConv(pdcnet: PDCNetAux, workspace: str, video, frames, kernel_size: int = 17, stride: int = 8, dilation: int = 2,
+                 save_pairs: bool = True):
+    """The reference's spelling (ofgen_keyframe_inpaint.py:655-674) with the reference's side effect: every pair it computes is
+    left in the `pdcnet/{s:05d}-{t:05d}.npy` cache (:600), so later `calculate_multiple_to_one` calls find it.  `keyframe_conv`
+    is the same computation without the 4.7 MB-per-pair dump."""
+    return keyframe_conv(pdcnet, workspace, video, frames, kernel_size, stride, dilation, save_pairs=save_pairs)

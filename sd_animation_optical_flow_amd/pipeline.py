@@ -54,10 +54,16 @@ class ClipPipeline:
         self.batch, self.warp_mode, self.thres, self.ksize, self.mask_blur = int(batch), warp_mode, float(thres), int(ksize), float(mask_blur)
         self.device = algo.device
 
-    def key_frame_flags(self, video, th: float = 8.5, keep_every: int = 1) -> List[bool]:
-        frames = (video.get_raw_frame(i) for i in range(video.num_frames))
-        return [k for _, k, _ in keyframes.frame_generator(frames, fps=getattr(video, "fps", 30.0) * keep_every, th=th,
-                                                           keep_every=keep_every, device=self.device)]
+    def key_frame_flags(self, video, th: float = 8.5) -> List[bool]:
+        """One flag per WORKSPACE frame (flags[i] belongs to `video.get_raw_frame(i)`).  The workspace is already decimated
+        (`keep_every` was applied when it was extracted, ofgen_keyframe_inpaint.py:342-368), so every frame is examined here and
+        the reference's 3601-frame cap of the extraction loop does not apply."""
+        n = video.num_frames
+        frames = (video.get_raw_frame(i) for i in range(n))
+        flags = [k for _, k, _ in keyframes.frame_generator(frames, fps=getattr(video, "fps", 30.0), th=th, keep_every=1,
+                                                           device=self.device, max_decoded=n)]
+        assert len(flags) == n, (len(flags), n)
+        return flags
 
     @torch.no_grad()
     def packets(self, video, flags: List[bool]):

@@ -16,19 +16,29 @@ import torch.nn.functional as F
 from . import _lib
 from ._lib import check
 
-FLAG_BGR, FLAG_SHARED_IMG2, FLAG_SHARED_IMG1, FLAG_ALT_CORR, FLAG_BF16X3, FLAG_SERIAL, FLAG_BF16X6 = 1, 2, 4, 8, 16, 32, 64
+FLAG_BGR, FLAG_SHARED_IMG2, FLAG_SHARED_IMG1, FLAG_ALT_CORR, FLAG_BF16X3, FLAG_SERIAL, FLAG_BF16X6, FLAG_BN_BATCH, FLAG_SEPARATE_STATS = 1, 2, 4, 8, 16, 32, 64, 128, 256
+CNET_NORMS = {"eval": 0, "batch": FLAG_BN_BATCH}
 PRECISIONS = {"fp32": 0, "bf16x3": FLAG_BF16X3, "bf16x6": FLAG_BF16X6}
 
 
 class RaftEngine:
-    def __init__(self, state_dict: Dict[str, torch.Tensor], device: Optional[torch.device] = None, precision: str = "fp32"):
-        """precision: 'fp32' (default; exact fp32 matrix-core arithmetic, the reference's), 'bf16x3' (opt-in fast
+    def __init__(self, state_dict: Dict[str, torch.Tensor], device: Optional[torch.device] = None, precision: str = "fp32",
+                 cnet_norm: str = "eval"):
+        """cnet_norm: how the context encoder's BatchNorm layers (RAFT/core/raft.py:55) are evaluated.  'eval' (default):
+        with their running statistics, folded into the convolutions -- a model in `.eval()`, what PDCNet's own code does
+        (pdcnet_of.py:62) and canonical RAFT inference.  'batch': with the statistics of the image itself -- the
+        reference's `RAFT_2` AS WRITTEN, which never calls `.eval()` (ofgen_keyframe_inpaint.py:47-60) and feeds one image
+        per call; every image of a batch is normalised by itself, so a batch equals as many reference calls.
+        precision: 'fp32' (default; exact fp32 matrix-core arithmetic, the reference's), 'bf16x3' (opt-in fast
         mode: operands split into two bf16 values, three bf16 MFMAs per product, fp32 accumulate; flow EPE
         ~1e-4 px against the fp32 path) or 'bf16x6' (opt-in: three bf16 pieces = the fp32 value exactly, six
         products, fp32 accumulate: fp32-level accuracy on the bf16 matrix cores)."""
         if precision not in PRECISIONS:
             raise ValueError(f"precision must be one of {sorted(PRECISIONS)}")
+        if cnet_norm not in CNET_NORMS:
+            raise ValueError(f"cnet_norm must be one of {sorted(CNET_NORMS)}")
         self.precision = precision
+        self.cnet_norm = cnet_norm
         L = _lib.lib()
         if not torch.cuda.is_available():
             raise RuntimeError("RaftEngine needs a HIP device (no CPU fallback)")
@@ -98,17 +108,18 @@ class RaftEngine:
 
     @torch.no_grad()
     def forward(self, image1: torch.Tensor, image2: torch.Tensor, iters: int = 20, bgr: bool = False,
-                alternate_corr: bool = False, want_low: bool = False, serial: bool = False):
+                alternate_corr: bool = False, want_low: bool = False, serial: bool = False, separate_stats: bool = False):
         """image1: uint8 [B,H,W,3] or [H,W,3] (shared by the batch); image2 likewise.  Flow is defined
         on image1's grid and points into image2.  Returns flow_up f32[B,H,W,2] (and flow_low).
         serial=True keeps every launch on the current stream (small batches otherwise overlap their
-        independent chains on the engine's side streams; results are identical)."""
+        independent chains on the engine's side streams; results are identical).  separate_stats=True (diagnostic) takes the
+        instance-norm statistics with their own f64 pass instead of out of the convolution epilogues."""
         for nm, t in (("image1", image1), ("image2", image2)):
             if not t.is_cuda:
                 raise RuntimeError(f"{nm} must be a CUDA tensor")
             if t.dtype != torch.uint8:
                 raise RuntimeError(f"{nm} must be uint8")
-        flags = (FLAG_BGR if bgr else 0) | PRECISIONS[self.precision] | (FLAG_SERIAL if serial else 0)
+        flags = (FLAG_BGR if bgr else 0) | PRECISIONS[self.precision] | (FLAG_SERIAL if serial else 0) | CNET_NORMS[self.cnet_norm] | (FLAG_SEPARATE_STATS if separate_stats else 0)
         sh1, sh2 = image1.dim() == 3, image2.dim() == 3
         if sh1 and sh2:
             image1, sh1 = image1[None], False
@@ -133,7 +144,7 @@ class RaftEngine:
             for b0 in range(0, B, max_pairs):
                 a = image1 if sh1 else image1[b0:b0 + max_pairs]
                 c = image2 if sh2 else image2[b0:b0 + max_pairs]
-                r = self.forward(a, c, iters=iters, bgr=bgr, alternate_corr=alternate_corr, want_low=want_low, serial=serial)
+                r = self.forward(a, c, iters=iters, bgr=bgr, alternate_corr=alternate_corr, want_low=want_low, serial=serial, separate_stats=separate_stats)
                 ups.append(r[0] if want_low else r)
                 if want_low:
                     lows.append(r[1])
@@ -174,7 +185,8 @@ class RaftEngine:
         flow_up = torch.empty((B, H, W, 2), dtype=torch.float32, device=self.device)
         stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
         check(L.ofx_raft_forward_pairs(self._h, C.c_void_p(imgs.data_ptr()), n, a1, a2, B, H, W, int(iters),
-                                       (FLAG_BGR if bgr else 0) | PRECISIONS[self.precision], C.c_void_p(flow_up.data_ptr()), None,
+                                       (FLAG_BGR if bgr else 0) | PRECISIONS[self.precision] | CNET_NORMS[self.cnet_norm],
+                                       C.c_void_p(flow_up.data_ptr()), None,
                                        C.c_void_p(self._ws.data_ptr()), self._ws.numel(), stream), "ofx_raft_forward_pairs")
         return flow_up
 

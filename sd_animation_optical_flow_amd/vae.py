@@ -132,6 +132,13 @@ class VaeEncoder:
         a = ops.attention(q, k, v, None, float(Cn) ** -0.5).reshape(B, H, W, Cn)
         return self._conv(f"{name}.proj_out", a, 1, addend=x)
 
+    def max_batch(self, H: int, W: int) -> int:
+        """Images one pass of the encoder can take at this size: the convolution kernel addresses its operands with 32-bit byte
+        offsets, so the widest activation -- the full-resolution `ch * ch_mult[0]`-channel maps of level 0 -- must stay under
+        2 GiB (10 frames at 512x768, 4 at 1024x1024).  `encode_moments` slices larger batches (images are independent)."""
+        widest = H * W * self.cfg["ch"] * max(1, self.cfg["ch_mult"][0]) * 4
+        return max(1, ((1 << 31) - 4096) // widest)
+
     @torch.no_grad()
     def encode_moments(self, image: torch.Tensor) -> torch.Tensor:
         """image f32 [B,3,H,W] in [-1,1] (what img2img_inpaint builds, guided_ldm_inpainting.py:299-301), H and W
@@ -142,6 +149,9 @@ class VaeEncoder:
         n_down = len(self.cfg["ch_mult"]) - 1
         if H % (1 << n_down) or W % (1 << n_down):
             raise RuntimeError(f"H and W must be multiples of {1 << n_down}")
+        mb = self.max_batch(H, W)
+        if B > mb:
+            return torch.cat([self.encode_moments(image[b0:b0 + mb]) for b0 in range(0, B, mb)])
         x = torch.zeros((B, H, W, 4), dtype=torch.float32, device=image.device)        # NHWC, channel 3 = 0 (Cin padded to 4)
         x[..., :3] = image.permute(0, 2, 3, 1)
         h = self._conv("encoder.conv_in", x, 3)

@@ -12,6 +12,13 @@ What it pins
                          step, the convex upsample, and the final 20-iteration flow.
                          Also asserts, at generation time, that the oracle restatement reproduces every
                          one of them (so a stale oracle cannot ship).
+  raft_ref_trainbn_128x160.npz
+                         the same reference module driven EXACTLY as `RAFT_2` drives it (ofgen_keyframe_inpaint.py:47-71):
+                         `DataParallel(RAFT(args))`, `load_state_dict`, NO `.eval()` -- so the context encoder's BatchNorm
+                         layers run in train mode on the call's one image -- `InputPadder`, `iters=20, test_mode=True`,
+                         `flow_up[0].permute(1,2,0)` without un-padding.  Two BGR frame pairs: 128x160 and 132x156 (padded
+                         to 136x160; the reference itself returns NaN once a pyramid level is one pixel wide --
+                         `bilinear_sampler` divides by W-1, utils.py:62-63 -- i.e. for frames under 128 px).  Asserts that `oracle.raft_oracle.raft2_calc(cnet_norm="batch")` reproduces both.
   warp_grid_sample.npz   torch.nn.functional.grid_sample (bilinear / bicubic, zeros, align_corners=True)
                          outputs for the warp modes that have an importable third-party implementation.
   cv2_semantics.npz      cv2 is not installed anywhere we can reach and is un-pinned upstream ("exact-cv2
@@ -128,6 +135,51 @@ def make_raft():
     np.savez_compressed(os.path.join(HERE, "raft_ref_128x160.npz"), **out)
 
 
+def make_raft_trainbn():
+    warnings.filterwarnings("ignore")
+    sys.path.insert(0, REF)
+    from raft import RAFT
+    from utils.utils import InputPadder
+
+    class NS:
+        def __contains__(self, m):
+            return hasattr(self, m)
+    a = NS()
+    a.small, a.mixed_precision, a.alternate_corr = False, False, False
+    model = torch.nn.DataParallel(RAFT(a))                       # RAFT_2.__init__: wrapped, loaded, never .eval()'d
+    sd = RO.init_state_dict(0)
+    model.load_state_dict({"module." + k: v for k, v in sd.items()}, strict=True)
+    assert model.training and model.module.cnet.norm1.training
+
+    out = {"state_dict_sha256": sd_digest(sd)}
+    for tag, (H, W), seed in (("a", (128, 160), 21), ("b", (132, 156), 22)):
+        g = torch.Generator().manual_seed(seed)
+        base = F.avg_pool2d(torch.rand((1, 3, H + 16, W + 16), generator=g), 5, 1, 2)
+        base = ((base - base.min()) / (base.max() - base.min()) * 255).round().to(torch.uint8)
+        f1 = base[0, :, 8:8 + H, 8:8 + W].permute(1, 2, 0).contiguous().numpy()      # "BGR" frames as cv2.imread hands them over
+        f2 = base[0, :, 11:11 + H, 6:6 + W].permute(1, 2, 0).contiguous().numpy()
+        with torch.no_grad():                                    # RAFT_2.calc, cv2.cvtColor(BGR2RGB) = channel reversal
+            i1 = torch.from_numpy(np.ascontiguousarray(f1[:, :, ::-1])).permute(2, 0, 1).float()[None]
+            i2 = torch.from_numpy(np.ascontiguousarray(f2[:, :, ::-1])).permute(2, 0, 1).float()[None]
+            padder = InputPadder(i1.shape)
+            p1, p2 = padder.pad(i1, i2)
+            flow_low, flow_up = model(p1, p2, iters=20, test_mode=True)
+            flo = flow_up[0].permute(1, 2, 0).cpu().numpy()
+            cn = model.module.cnet(2 * (p1 / 255.0) - 1.0)       # train-mode BatchNorm on this one image
+            net, inp = torch.tanh(cn[:, :128]), torch.relu(cn[:, 128:])
+        mine = RO.raft2_calc(sd, f1, f2, iters=20, cnet_norm="batch")
+        assert mine.shape == flo.shape
+        epe = float(np.sqrt(((mine - flo) ** 2).sum(-1)).mean())
+        ev = RO.raft2_calc(sd, f1, f2, iters=20, cnet_norm="eval")
+        gap = float(np.sqrt(((ev - flo) ** 2).sum(-1)).mean())
+        print(f"train-mode BN [{tag}] {H}x{W}: oracle(batch) vs reference RAFT_2 EPE {epe:.3e} px; eval-mode oracle is {gap:.3e} px away")
+        assert epe < 1e-4 and gap > 10 * epe
+        out.update({f"frame1_{tag}": f1, f"frame2_{tag}": f2, f"flow_{tag}": flo, f"flow_low_{tag}": flow_low.numpy(),
+                    f"net_f16_{tag}": net.numpy().astype(np.float16), f"inp_f16_{tag}": inp.numpy().astype(np.float16),
+                    f"eval_gap_{tag}": np.float32(gap)})
+    np.savez_compressed(os.path.join(HERE, "raft_ref_trainbn_128x160.npz"), **out)
+
+
 def make_warp():
     rng = np.random.default_rng(3)
     H, W = 40, 56
@@ -167,8 +219,13 @@ def make_warp():
 if __name__ == "__main__":
     if not os.path.isdir(REF):
         sys.exit("the reference is not mounted here; golden vectors can only be regenerated in the build container")
-    make_raft()
-    make_warp()
+    only = sys.argv[1:]
+    if not only or "raft" in only:
+        make_raft()
+    if not only or "trainbn" in only:
+        make_raft_trainbn()
+    if not only or "warp" in only:
+        make_warp()
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(HERE, f)) // 1024, "KiB")

@@ -166,7 +166,7 @@ def test_bf16x6_mode_matches_fp32_to_rounding_level(cuda, raft_sd, engine):
 def test_non_multiple_of_8_is_padded_like_input_padder(engine, raft_sd):
     H, W = 100, 90
     key, frames = _frames(5, 1, H, W)
-    ref = RO.raft2_calc(raft_sd, frames[0].flip(-1).numpy(), key.flip(-1).numpy(), iters=4)
+    ref = RO.raft2_calc(raft_sd, frames[0].flip(-1).numpy(), key.flip(-1).numpy(), iters=4, cnet_norm="eval")
     up = engine.forward(frames.flip(-1).contiguous().cuda(), key.flip(-1).contiguous().cuda()[None], iters=4, bgr=True)
     assert tuple(up.shape[1:3]) == ref.shape[:2] == (104, 96)      # the reference does not un-pad
     assert _epe(up[0].cpu(), torch.from_numpy(ref)) < 1e-3
@@ -321,3 +321,87 @@ def test_saturated_gates_stay_inside_the_bar(cuda, raft_sd):
     assert (lo.cpu() - lo_ref).abs().max().item() < 5e-3
     assert hx[:, :128].abs().max().item() <= 1.0 + 1e-6          # h is a convex mix of tanh values
     print(f"saturated fraction of the hidden state after iteration 0: {sat:.3f}")
+
+
+# ------------------------------------------------------------------------------------------------
+# round 3: a float64 yardstick under the headline-size parity, degenerate inputs for the epilogue statistics
+# ------------------------------------------------------------------------------------------------
+def test_headline_size_parity_against_a_float64_yardstick(engine, raft_sd):
+    """At the benchmarked size the HIP flow sits 2-3e-4 px from the fp32 CPU oracle, the small tests 3e-6: which of the two
+    drifts?  The same network evaluated in float64 (oracle.raft_oracle.to_float64) is the yardstick: over 20 recurrent
+    iterations on the bench clip's frames the HIP path must be no further from it than 1.5x what the fp32 CPU oracle is,
+    and inside the 1e-3 px bar by itself.  tools/epe_curve.py prints the per-iteration curve (profiles/r03_epe_curve.txt)."""
+    import bench
+    H, W = bench.H, bench.W
+    frames, key, _, _ = bench.make_clip(64, H, W, torch.device("cuda"))
+    sd64 = RO.to_float64(raft_sd)
+    kf = key.cpu().permute(2, 0, 1)[None].float()
+    flow = engine.forward(frames, key, iters=bench.ITERS)
+    for b in (0, 31, 63):
+        a = frames[b].cpu().permute(2, 0, 1)[None].float()
+        _, up32 = RO.raft_forward(raft_sd, a, kf, iters=bench.ITERS)
+        _, up64 = RO.raft_forward(sd64, a.double(), kf.double(), iters=bench.ITERS)
+        r64 = up64[0].permute(1, 2, 0)
+        e_gpu = _epe(flow[b].cpu().double(), r64)
+        e_cpu = _epe(up32[0].permute(1, 2, 0).double(), r64)
+        print(f"pair {b}: HIP vs f64 {e_gpu:.3e} px, fp32 CPU oracle vs f64 {e_cpu:.3e} px")
+        assert e_gpu < 1e-3, (b, e_gpu)
+        assert e_gpu <= 1.5 * e_cpu + 2e-5, (b, e_gpu, e_cpu)
+
+
+def _degenerate_frames(kind, B, H, W, seed=3):
+    g = torch.Generator().manual_seed(seed)
+    if kind == "constant":                       # zero variance everywhere but at the zero-padded borders
+        a = torch.full((B, H, W, 3), 200, dtype=torch.uint8)
+        k = torch.full((H, W, 3), 200, dtype=torch.uint8)
+    elif kind == "one_lsb":                      # sigma <= 1 LSB around a large mean: sum x^2 / n - mu^2 cancels
+        a = (200 + torch.randint(0, 2, (B, H, W, 3), generator=g)).to(torch.uint8)
+        k = (200 + torch.randint(0, 2, (H, W, 3), generator=g)).to(torch.uint8)
+    elif kind == "saturated":                    # 0 / 255 only
+        a = (torch.randint(0, 2, (B, H, W, 3), generator=g) * 255).to(torch.uint8)
+        k = (torch.randint(0, 2, (H, W, 3), generator=g) * 255).to(torch.uint8)
+    elif kind == "bright":
+        a = (250 + torch.randint(0, 6, (B, H, W, 3), generator=g)).to(torch.uint8)
+        k = (250 + torch.randint(0, 6, (H, W, 3), generator=g)).to(torch.uint8)
+    else:                                        # half flat, half texture
+        a = torch.randint(0, 256, (B, H, W, 3), generator=g).to(torch.uint8)
+        k = torch.randint(0, 256, (H, W, 3), generator=g).to(torch.uint8)
+        a[:, :, : W // 2] = 17
+        k[:, : W // 2] = 17
+    return a.contiguous(), k.contiguous()
+
+
+@pytest.mark.parametrize("kind", ["constant", "one_lsb", "saturated", "bright", "half_flat"])
+@pytest.mark.parametrize("cnet_norm", ["eval", "batch"])
+def test_epilogue_statistics_on_degenerate_frames(cuda, raft_sd, kind, cnet_norm):
+    """The feature encoder's instance-norm statistics (and the context encoder's in 'batch' mode) come out of the convolution
+    epilogues as per-wave fp32 (sum, sum of squares), var = q/HW - mu^2 (conv.hip, net_misc.hip): the inputs that can break
+    that are maps with (almost) no variance.  Feature maps after the encoders against the oracle, the 12-iteration flow against
+    the oracle, and both against the schedule that takes the statistics with their own f64 pass."""
+    from sd_animation_optical_flow_amd.raft import RaftEngine
+    eng = RaftEngine(raft_sd, cnet_norm=cnet_norm)
+    B, H, W, iters = 2, 256, 384, 12
+    a, k = _degenerate_frames(kind, B, H, W)
+    tr = {}
+    lo_ref, up_ref = RO.raft_forward(raft_sd, a.permute(0, 3, 1, 2).float(), k.permute(2, 0, 1)[None].repeat(B, 1, 1, 1).float(),
+                                     iters=iters, trace=tr, cnet_norm=cnet_norm)
+    up_ref = up_ref.permute(0, 2, 3, 1)
+    res = {}
+    for sep in (False, True):
+        up = eng.forward(a.cuda(), k.cuda(), iters=iters, separate_stats=sep)
+        assert torch.isfinite(up).all()
+        fm1 = eng.buffer("fmap1").cpu().reshape(B, H // 8, W // 8, 256)
+        hx = eng.buffer("hx").cpu().reshape(B, H // 8, W // 8, 384)
+        res[sep] = (up.cpu(), fm1, hx[..., 256:])
+    fm_ref = tr["fmap1"].permute(0, 2, 3, 1)
+    inp_ref = tr["inp"].permute(0, 2, 3, 1)
+    scale = max(1.0, fm_ref.abs().max().item())
+    for sep in (False, True):
+        up, fm1, inp = res[sep]
+        # on (almost) flat maps the normalisation divides rounding noise by sqrt(var + 1e-5): the oracle's own fp32 statistics are
+        # no better placed than ours, so the feature maps are held to the oracle loosely and to each other tightly (below)
+        assert (fm1 - fm_ref).abs().max().item() < 5e-3 * scale, (sep, (fm1 - fm_ref).abs().max().item())
+        assert (inp - inp_ref).abs().max().item() < 5e-3 * max(1.0, inp_ref.abs().max().item())
+        assert _epe(up, up_ref) < 1e-3, (sep, _epe(up, up_ref))
+    assert (res[False][1] - res[True][1]).abs().max().item() < 2e-3 * scale
+    assert _epe(res[False][0], res[True][0]) < 5e-4

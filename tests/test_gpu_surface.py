@@ -37,10 +37,10 @@ def test_calc_contract_and_flow_orientation(algo, raft_sd):
     assert conf.min() >= 0 and conf.max() <= 1 and logc.max() <= 0
     assert np.allclose(np.exp(logc), conf, atol=1e-6)
     # flow lives on frame2's grid and points into frame1 == RAFT(image1=frame2, image2=frame1) on RGB
-    ref = RO.raft2_calc(raft_sd, f2, f1)
+    ref = RO.raft2_calc(raft_sd, f2, f1, cnet_norm="eval")   # the pdcnet_of surface runs its network in .eval() (pdcnet_of.py:62)
     assert np.sqrt(((flow - ref) ** 2).sum(-1)).mean() < 1e-3
     # forward-backward confidence (extension) against a numpy restatement built from oracle flows
-    bw = RO.raft2_calc(raft_sd, f1, f2)
+    bw = RO.raft2_calc(raft_sd, f1, f2, cnet_norm="eval")
     samp = WO.warp_frame(bw, ref, mode="bilinear")
     e = ref + samp
     want = np.exp(-(e ** 2).sum(-1) / (2 * 3.0 ** 2))
@@ -249,6 +249,50 @@ def test_full_hd_frame_single_pair(cuda, raft_sd):
     assert (got - ref).abs().max().item() < 1e-4 * max(1.0, ref.abs().max().item())
 
 
+def test_raft2_as_written_against_the_reference_train_mode_vectors(cuda, raft_sd):
+    """ofgen.RAFT_2 (default cnet_norm='batch') against what the REAL reference RAFT returned when driven exactly as
+    `RAFT_2` drives it -- DataParallel, never `.eval()`, InputPadder, 20 iterations, no un-padding
+    (tests/golden/raft_ref_trainbn_128x160.npz, made by make_golden.py from /root/reference).  One hop, no oracle."""
+    import os
+    from sd_animation_optical_flow_amd import ofgen
+    from sd_animation_optical_flow_amd.raft import RaftEngine
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "raft_ref_trainbn_128x160.npz"))
+    r2 = ofgen.RAFT_2(model=raft_sd)
+    assert r2.model.cnet_norm == "batch"
+    for tag in ("a", "b"):
+        flo = r2.calc(g[f"frame1_{tag}"], g[f"frame2_{tag}"])
+        ref = g[f"flow_{tag}"]
+        assert flo.shape == ref.shape and flo.dtype == np.float32          # 132x156 comes back padded to 136x160
+        epe = np.sqrt(((flo - ref) ** 2).sum(-1)).mean()
+        assert epe < 1e-3 and np.abs(flo - ref).max() < 1e-2, (tag, epe)
+    # the context features themselves (half-precision fixture), straight from the engine's state buffer
+    hx = r2.model.buffer("hx").cpu().reshape(17 * 20, 384)
+    net = hx[:, :128].T.reshape(128, 17, 20)
+    inp = hx[:, 256:].T.reshape(128, 17, 20)
+    assert (inp - torch.from_numpy(g["inp_f16_b"][0].astype(np.float32))).abs().max().item() < 2e-2
+    del net                                                                # h has been through 20 GRU updates by now
+    # the opt-in eval mode is the OTHER network on these weights: pixels away from the as-written reference
+    ev = ofgen.RAFT_2(model=raft_sd, cnet_norm="eval").calc(g["frame1_a"], g["frame2_a"])
+    assert np.sqrt(((ev - g["flow_a"]) ** 2).sum(-1)).mean() > 1.0
+    # a batch is as many single-image reference calls: every image normalised by itself, also next to a shared key frame
+    eng = RaftEngine(raft_sd, cnet_norm="batch")
+    fr = torch.from_numpy(np.stack([g["frame1_a"], g["frame2_a"], g["frame1_a"][::-1].copy()])).cuda()
+    key = torch.from_numpy(g["frame2_a"]).cuda()
+    up = eng.forward(fr, key, iters=20, bgr=True)
+    assert np.sqrt(((up[0].cpu().numpy() - g["flow_a"]) ** 2).sum(-1)).mean() < 1e-3
+    for i in (1, 2):
+        one = eng.forward(fr[i:i + 1], key[None], iters=20, bgr=True)
+        assert (up[i] - one[0]).abs().max().item() < 2e-3
+    # key frame as image1 (the PDCNet orientation): ONE context map shared by the batch
+    sh = eng.forward(key, fr, iters=20, bgr=True)
+    one = eng.forward(key[None], fr[2:3], iters=20, bgr=True)
+    assert (sh[2] - one[0]).abs().max().item() < 2e-3
+    # indexed pairs (KeyframeConv's sweep) take the same switch
+    imgs = torch.cat([fr[:2], key[None]])
+    fp = eng.forward_pairs(imgs, [0, 1], [1, 0], iters=20, bgr=True)
+    assert np.sqrt(((fp[0].cpu().numpy() - g["flow_a"]) ** 2).sum(-1)).mean() < 1e-3
+
+
 def test_calc_returns_the_unpadded_size_for_frames_not_divisible_by_8(algo, raft_sd):
     """pdcnet_of.py:72-75 promises [H,W] outputs.  The network runs on the replicate-padded grid (InputPadder 'sintel',
     utils.py:9-16); flow, confidence and log-confidence must be cropped back -- RAFT_2.calc alone keeps the padded size
@@ -256,7 +300,7 @@ def test_calc_returns_the_unpadded_size_for_frames_not_divisible_by_8(algo, raft
     f1, f2 = _pair(9, H=100, W=90)
     flow, conf, logc = algo.calc(f1, f2)
     assert flow.shape == (100, 90, 2) and conf.shape == (100, 90) and logc.shape == (100, 90)
-    ref = RO.raft2_calc(raft_sd, f2, f1)                     # padded: 104 x 96, offsets (2, 3)
+    ref = RO.raft2_calc(raft_sd, f2, f1, cnet_norm="eval")   # padded: 104 x 96, offsets (2, 3)
     assert ref.shape[:2] == (104, 96)
     assert np.sqrt(((flow - ref[2:102, 3:93]) ** 2).sum(-1)).mean() < 1e-3
     # warp / mask on the cropped outputs line up with the frame again

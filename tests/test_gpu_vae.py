@@ -85,6 +85,8 @@ def test_fused_attention_randomised_sweep(cuda):
 
 def test_xformers_shim_on_the_device(cuda):
     """The call exactly as ldm/modules/attention.py:314 makes it: [b*heads, n, dim_head] half tensors and a 2-D bias."""
+    import os, sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "shims"))
     import xformers.ops
     g = torch.Generator().manual_seed(9)
     q, k, v = (torch.randn((8, 64, 40), generator=g) for _ in range(3))
@@ -144,3 +146,17 @@ def test_vae_encoder_1024x1024_hand_off(vae_enc):
     z = vae_enc.get_first_stage_encoding(t["image"])
     assert tuple(z.shape) == (1, 4, H // 8, W // 8) and bool(torch.isfinite(z).all())
     assert tuple(t["latmask"].shape) == (1, 4, H // 8, W // 8)
+
+
+def test_vae_encoder_slices_batches_beyond_the_2gib_activation_limit(vae_enc):
+    """ClipPipeline hands the encoder up to 64 frames at once; conv_in's [B,H,W,128] output crosses the convolution kernel's
+    32-bit byte offsets at 11 frames of 512x768.  `encode_moments` slices (images are independent): 12 frames at 512x768
+    come back, and equal the frames encoded one by one."""
+    assert vae_enc.max_batch(768, 512) == 10 and vae_enc.max_batch(1024, 1024) == 3
+    g = torch.Generator(device="cuda").manual_seed(9)
+    image = torch.rand((12, 3, 768, 512), device="cuda", generator=g) * 2 - 1
+    mo = vae_enc.encode_moments(image)
+    assert tuple(mo.shape) == (12, 8, 96, 64) and bool(torch.isfinite(mo).all())
+    for b in (0, 10, 11):
+        one = vae_enc.encode_moments(image[b:b + 1])
+        assert (mo[b:b + 1] - one).abs().max().item() < 1e-4 * max(1.0, one.abs().max().item())

@@ -232,3 +232,24 @@ def test_local_corr_backward_is_the_adjoint_of_the_pinned_forward():
     g1, g2, gc = RO.local_corr_backward(f1.detach(), f2.detach(), coords, gout, r)
     assert (g1 - a1).abs().max().item() < 1e-5 and (g2 - a2).abs().max().item() < 1e-5
     assert gc.shape == coords.shape and float(gc.abs().max()) == 0.0
+
+
+def test_raft2_as_written_train_mode_batchnorm_matches_reference_vectors(raft_sd):
+    """`RAFT_2` never calls `.eval()` (ofgen_keyframe_inpaint.py:47-60): raft_ref_trainbn_128x160.npz holds what the REAL
+    reference module returns when driven exactly like that (train-mode BatchNorm in the context encoder, one image per call).
+    The oracle's cnet_norm='batch' mode must reproduce it; the eval-mode oracle must not (the two are pixels apart)."""
+    g = _load("raft_ref_trainbn_128x160.npz")
+    for tag in ("a", "b"):
+        f1, f2, ref = g[f"frame1_{tag}"], g[f"frame2_{tag}"], g[f"flow_{tag}"]
+        got = RO.raft2_calc(raft_sd, f1, f2, iters=20, cnet_norm="batch")
+        assert got.shape == ref.shape
+        assert np.sqrt(((got - ref) ** 2).sum(-1)).mean() < 1e-4
+    f1, f2, ref = g["frame1_a"], g["frame2_a"], g["flow_a"]
+    ev = RO.raft2_calc(raft_sd, f1, f2, iters=20, cnet_norm="eval")
+    assert np.sqrt(((ev - ref) ** 2).sum(-1)).mean() > 1.0
+    # a batch in 'batch' mode = as many single-image reference calls (every image normalised by itself)
+    a = torch.from_numpy(np.stack([f1[:, :, ::-1], g["frame2_a"][:, :, ::-1]]).copy()).permute(0, 3, 1, 2).float()
+    b = torch.from_numpy(np.stack([f2[:, :, ::-1], g["frame1_a"][:, :, ::-1]]).copy()).permute(0, 3, 1, 2).float()
+    _, up = RO.raft_forward(raft_sd, a, b, iters=3, cnet_norm="batch")
+    _, up0 = RO.raft_forward(raft_sd, a[:1], b[:1], iters=3, cnet_norm="batch")
+    assert (up[:1] - up0).abs().max().item() < 1e-4

@@ -1,6 +1,6 @@
 """CPU: the first-stage (VAE) oracle against the vectors the REAL reference encoder produced (tests/golden/
 make_golden_vae.py), the product's seeded weights against the oracle's, the attention oracle against torch's SDPA, and
-the top-level `xformers` shim the reference's `ldm/` imports."""
+the `shims/xformers` shim the reference's `ldm/` imports."""
 import os
 
 import numpy as np
@@ -44,11 +44,15 @@ def test_attention_oracle_matches_torch_sdpa():
 
 
 def test_xformers_shim_resolves_to_the_hip_attention():
-    """ldm/modules/attention.py:12-18 does `import xformers; import xformers.ops`: with the repository root on sys.path
+    """ldm/modules/attention.py:12-18 does `import xformers; import xformers.ops`: with <repo>/shims on sys.path
     those imports resolve to this repository's shim (no compute here: no GPU)."""
+    import os, sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "shims"))
     import xformers
     import xformers.ops
     from sd_animation_optical_flow_amd import attention
     assert xformers.ops.memory_efficient_attention is attention.memory_efficient_attention
     with pytest.raises(RuntimeError):
         xformers.ops.memory_efficient_attention(torch.zeros(2, 4, 8), torch.zeros(2, 4, 8), torch.zeros(2, 4, 8))   # CPU tensors
+    with pytest.raises(TypeError):
+        xformers.ops.memory_efficient_attention(torch.zeros(2, 4, 8), torch.zeros(2, 4, 8), torch.zeros(2, 4, 8), attn_bias=object())
