@@ -477,6 +477,17 @@ def main():
             tp = tps[-1]
             tr = json.load(open(tp))
             src = f"profile: profiles/{os.path.basename(tp)} (committed rocprofv3 --pmc passes, not collected in this run)"
+            # tie the profile to the binary being timed: the round tag / source revision it was taken at, and whether the
+            # libofx.so it ran is byte for byte the one loaded here (a stale profile then says so itself)
+            import hashlib
+            meta = tr.pop("_profile", None) or {}
+            try:
+                here = hashlib.sha256(open(os.path.join(ROOT, "sd_animation_optical_flow_amd", "libofx.so"), "rb").read()).hexdigest()
+            except OSError:
+                here = None
+            out["traffic_profile"] = {"file": f"profiles/{os.path.basename(tp)}", "tag": meta.get("tag"), "git_rev": meta.get("git_rev"),
+                                      "libofx_sha256": meta.get("libofx_sha256"), "timed_libofx_sha256": here,
+                                      "same_binary": bool(here) and here == meta.get("libofx_sha256")}
             if "roofline" in out and "igemm_conv_all" in tr:
                 out["roofline"]["traffic"] = tr["igemm_conv_all"]["hbm_bytes_per_launch_corrected"]
                 out["roofline"]["traffic_source"] = src

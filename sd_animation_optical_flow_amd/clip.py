@@ -50,6 +50,62 @@ def broadcast_keyframe(tensors: Sequence[torch.Tensor], src: int = 0, group=None
 
 
 @dataclass
+class SegmentPlan:
+    """One key frame and the frames that follow it up to the next key frame, spread over the ranks."""
+    key: int                           # workspace index of the key frame
+    owner: int                         # rank that renders the key frame (and broadcasts it when the segment is split)
+    frames: List[List[int]]            # per rank: the segment's frame indices that rank processes (possibly empty)
+
+    @property
+    def ranks(self) -> List[int]:
+        return [r for r, f in enumerate(self.frames) if f]
+
+    @property
+    def needs_broadcast(self) -> bool:
+        return any(r != self.owner for r in self.ranks)
+
+
+def plan_segments(flags: Sequence[bool], world: int) -> List[SegmentPlan]:
+    """Key-frame segments -> ranks.  Segment lengths are content-dependent (the detector's gaps,
+    ofgen_keyframe_inpaint.py:443-469), so contiguous frame blocks would leave ranks idle: segments are taken longest first
+    and poured into the least-loaded rank up to ceil(frames / world) -- whole segments stay on one rank (no exchange at all)
+    wherever the balance allows, a segment is cut only when it must be, and then the rank holding its largest piece
+    renders the key frame and broadcasts it.  Deterministic: every rank computes the same plan from the same flags.
+    Returned in key-frame order."""
+    if world <= 0:
+        raise ValueError(f"bad world size {world}")
+    n = len(flags)
+    if n and not flags[0]:
+        raise ValueError("the first frame of a clip is a key frame")
+    segs = []
+    i = 0
+    while i < n:
+        j = i + 1
+        while j < n and not flags[j]:
+            j += 1
+        segs.append((i, list(range(i + 1, j))))
+        i = j
+    total = sum(len(f) for _, f in segs)
+    target = max(1, -(-total // world))
+    load = [0] * world
+    plans = []
+    for key, frames in sorted(segs, key=lambda kf: (-len(kf[1]), kf[0])):
+        per = [[] for _ in range(world)]
+        rest = frames
+        while rest:
+            r = min(range(world), key=lambda q: (load[q], q))
+            take = max(1, min(len(rest), target - load[r]))
+            per[r] = per[r] + rest[:take]
+            load[r] += take
+            rest = rest[take:]
+        # a key frame nobody warps from (two key frames in a row) still has to be rendered by someone
+        owner = max(range(world), key=lambda q: (len(per[q]), -q)) if frames else min(range(world), key=lambda q: (load[q], q))
+        plans.append(SegmentPlan(key, owner, per))
+    plans.sort(key=lambda p_: p_.key)
+    return plans
+
+
+@dataclass
 class SynthesisResult:
     frame_indices: List[int]
     flow: List[torch.Tensor]          # per batch: f32[b,H,W,2]

@@ -21,7 +21,7 @@ from typing import Callable, Dict, List, Optional
 import numpy as np
 import torch
 
-from . import handoff, keyframes, ops
+from . import clip, handoff, keyframes, ops
 
 
 @dataclass
@@ -44,15 +44,16 @@ def _paste_raw(pkt: FramePacket, raw_bgr: torch.Tensor) -> torch.Tensor:
 class ClipPipeline:
     """`algo`: a `pdcnet_of.PDCNetPlus`; `vae`: optional `vae.VaeEncoder`; `render(packet, raw_bgr) -> u8 [H,W,3]` turns a
     packet into the AI frame (default: `_paste_raw`); key frames are rendered by `render_key(raw_bgr) -> u8 [H,W,3]`
-    (default: identity).  `batch` frames share one executor call per key frame."""
+    (default: identity).  `batch` frames share one executor call per key frame.  Rank-aware: under an initialised
+    `torch.distributed` group every rank runs the same `run(video)` and takes its share (`packets`)."""
 
     def __init__(self, algo, vae=None, render: Optional[Callable] = None, render_key: Optional[Callable] = None, batch: int = 64,
-                 warp_mode: str = "bilinear", thres: float = 0.95, ksize: int = 7, mask_blur: float = 4.0):
+                 warp_mode: str = "bilinear", thres: float = 0.95, ksize: int = 7, mask_blur: float = 4.0, device=None):
         self.algo, self.vae = algo, vae
         self.render = render or _paste_raw
         self.render_key = render_key or (lambda raw: raw)
         self.batch, self.warp_mode, self.thres, self.ksize, self.mask_blur = int(batch), warp_mode, float(thres), int(ksize), float(mask_blur)
-        self.device = algo.device
+        self.device = device if device is not None else algo.device
 
     def key_frame_flags(self, video, th: float = 8.5) -> List[bool]:
         """One flag per WORKSPACE frame (flags[i] belongs to `video.get_raw_frame(i)`).  The workspace is already decimated
@@ -66,36 +67,52 @@ class ClipPipeline:
         return flags
 
     @torch.no_grad()
+    def process_batch(self, key_raw: torch.Tensor, key_ai: torch.Tensor, raws: torch.Tensor, ids: List[int], key_index: int):
+        """flow + confidence -> warp + mask -> SD-inpaint inputs for `raws` (u8 [b,H,W,3] BGR, device) against one key frame;
+        returns the packets.  The one compute step of the pipeline (tests of the rank logic substitute it on the CPU)."""
+        # source = key frame, target = frames: flow on each frame's grid pointing into the key frame (BGR in)
+        flow, conf, _ = self.algo.calc_batch_device(key_raw, raws, bgr=True)
+        warped, mask = ops.warp_and_mask(key_ai.contiguous(), flow.contiguous(), conf.contiguous(), warp_mode=self.warp_mode,
+                                         thres=self.thres, ksize=self.ksize)
+        inp = handoff.prepare_inpaint_inputs(warped, raws, mask, mask_blur=self.mask_blur, device=self.device)
+        if self.vae is not None:
+            inp["init_latent"] = self.vae.get_first_stage_encoding(inp["image"])
+        return [FramePacket(t, key_index, flow[k], conf[k], warped[k], mask[k], {name: v[k] for name, v in inp.items()})
+                for k, t in enumerate(ids)]
+
+    @torch.no_grad()
     def packets(self, video, flags: List[bool]):
-        """Yields (FramePacket | None, raw_bgr tensor, index): None for key frames."""
-        n = len(flags)
-        i = 0
-        while i < n:
-            assert flags[i], "the first frame of a segment is its key frame"
-            key_raw = torch.from_numpy(video.get_raw_frame(i)).to(self.device)
-            key_ai = self.render_key(key_raw)
-            video.put_ai_frame(i, key_ai.cpu().numpy())
-            yield None, key_raw, i
-            j = i + 1
-            while j < n and not flags[j]:
-                j += 1
-            for b0 in range(i + 1, j, self.batch):
-                ids = list(range(b0, min(j, b0 + self.batch)))
+        """Yields (FramePacket | None, raw_bgr tensor, index) for THIS rank's share of the clip: None for the key frames this
+        rank renders.  One process: everything.  Under `torch.distributed` (one process per GPU): `clip.plan_segments` spreads
+        the key-frame segments over the ranks; the rank that owns a segment renders its key frame, and only when a segment had
+        to be cut does the rendered key frame travel -- one `broadcast_keyframe` (RCCL on the `nccl` backend), the single
+        collective of the path.  Raw frames come from the workspace, which the ranks of a node share."""
+        rank, world = clip.dist_info()
+        for seg in clip.plan_segments(flags, world):
+            mine = seg.frames[rank]
+            owner = rank == seg.owner
+            if not (owner or mine or seg.needs_broadcast):
+                continue
+            shape = (*video.size_hw, 3)
+            key_raw = torch.from_numpy(video.get_raw_frame(seg.key)).to(self.device) if (owner or mine) else None
+            if owner:
+                key_ai = self.render_key(key_raw).contiguous()
+                video.put_ai_frame(seg.key, key_ai.cpu().numpy())
+                yield None, key_raw, seg.key
+            else:
+                key_ai = torch.empty(shape, dtype=torch.uint8, device=self.device)
+            if seg.needs_broadcast:
+                # the one collective of the path; every rank of the group takes part, also those with no frame of this segment
+                clip.broadcast_keyframe([key_ai], src=seg.owner)
+            for b0 in range(0, len(mine), self.batch):
+                ids = mine[b0:b0 + self.batch]
                 raws = torch.from_numpy(np.stack([video.get_raw_frame(t) for t in ids])).to(self.device)
-                # source = key frame, target = frames: flow on each frame's grid pointing into the key frame (BGR in)
-                flow, conf, _ = self.algo.calc_batch_device(key_raw, raws, bgr=True)
-                warped, mask = ops.warp_and_mask(key_ai.contiguous(), flow.contiguous(), conf.contiguous(), warp_mode=self.warp_mode,
-                                                 thres=self.thres, ksize=self.ksize)
-                inp = handoff.prepare_inpaint_inputs(warped, raws, mask, mask_blur=self.mask_blur, device=self.device)
-                if self.vae is not None:
-                    inp["init_latent"] = self.vae.get_first_stage_encoding(inp["image"])
-                for k, t in enumerate(ids):
-                    per = {name: v[k] for name, v in inp.items()}
-                    yield FramePacket(t, i, flow[k], conf[k], warped[k], mask[k], per), raws[k], t
-            i = j
+                for pkt, raw in zip(self.process_batch(key_raw, key_ai, raws, ids, seg.key), raws):
+                    yield pkt, raw, pkt.index
 
     def run(self, video, flags: Optional[List[bool]] = None) -> List[int]:
-        """Processes the whole workspace; writes `ai-frames/{n:05d}.png`; returns the key-frame indices."""
+        """Processes this rank's share of the workspace (all of it in one process); writes `ai-frames/{n:05d}.png` for the frames
+        it owns -- results stay with the owning rank; returns the key-frame indices this rank rendered."""
         flags = flags if flags is not None else self.key_frame_flags(video)
         keys = []
         for pkt, raw, idx in self.packets(video, flags):

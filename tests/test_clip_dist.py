@@ -117,3 +117,105 @@ def test_bench_refuses_to_measure_fewer_gpus_than_asked():
     # a launcher that started a different number of ranks than --gpus names is refused as well
     r = _run_bench(["--gpus", "4", "--stub-step"], env_extra={"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})
     assert r.returncode != 0 and "WORLD_SIZE=1" in r.stderr
+
+
+# ------------------------------------------------------------------------------------------------
+# round 3: the rank-aware clip driver over a workspace (pipeline.ClipPipeline + clip.plan_segments)
+# ------------------------------------------------------------------------------------------------
+def test_plan_segments_balances_content_dependent_segments():
+    def flags_of(lengths):                       # lengths = frames following each key frame
+        f = []
+        for n in lengths:
+            f += [True] + [False] * n
+        return f
+    for lengths, world in (([64] * 8, 8), ([100, 3, 3, 3, 3, 3, 3, 10], 4), ([5], 2), ([0, 0, 7], 2), ([1, 200, 1], 8), ([3, 2], 1)):
+        flags = flags_of(lengths)
+        plan = clip.plan_segments(flags, world)
+        assert [p.key for p in plan] == [i for i, k in enumerate(flags) if k]
+        seen = sorted(t for p in plan for per in p.frames for t in per)
+        assert seen == [i for i, k in enumerate(flags) if not k]                      # every frame exactly once
+        load = [sum(len(p.frames[r]) for p in plan) for r in range(world)]
+        assert max(load) <= -(-sum(lengths) // world)                                 # nobody above ceil(total / world)
+        for p in plan:
+            assert 0 <= p.owner < world
+            if any(p.frames):
+                assert p.frames[p.owner], "the owner of a key frame works on its segment"
+            for per in p.frames:                                                      # pieces are contiguous runs
+                assert per == list(range(per[0], per[0] + len(per))) if per else True
+    # BASELINE configs[3]: 8 key frames x 64 frames over 8 ranks = one whole segment per rank, no broadcast at all
+    plan = clip.plan_segments(flags_of([64] * 8), 8)
+    assert sorted(p.owner for p in plan) == list(range(8)) and not any(p.needs_broadcast for p in plan)
+    # one long segment has to be cut: it is broadcast, the short ones are not
+    plan = clip.plan_segments(flags_of([100, 3, 3]), 2)
+    assert plan[0].needs_broadcast and len(plan[0].ranks) == 2
+    with pytest.raises(ValueError):
+        clip.plan_segments([False, True], 2)
+
+
+class _StubPipeline:
+    """ClipPipeline with the compute step replaced by CPU arithmetic that depends on every input (frame, key frame, rendered
+    key frame): the rank logic, the workspace I/O and the broadcast are the real ones."""
+
+    @staticmethod
+    def make(device="cpu"):
+        from sd_animation_optical_flow_amd import pipeline
+
+        class P(pipeline.ClipPipeline):
+            def process_batch(self, key_raw, key_ai, raws, ids, key_index):
+                out = []
+                for k, t in enumerate(ids):
+                    warped = (raws[k] // 2 + key_ai // 4 + key_raw // 8).to(torch.uint8)
+                    mask = ((raws[k][..., 0] > 128).to(torch.uint8) * 255)
+                    out.append(pipeline.FramePacket(t, key_index, torch.zeros(1), torch.zeros(1), warped, mask, {}))
+                return out
+        render = lambda pkt, raw: torch.where(pkt.mask[..., None] > 0, raw, pkt.warped)
+        return P(algo=None, render=render, render_key=lambda raw: 255 - raw, batch=3, device=torch.device(device))
+
+
+def _make_workspace(path, n=23, H=16, W=24):
+    import numpy as np
+    from sd_animation_optical_flow_amd.workspace import VideoData
+    rng = np.random.default_rng(5)
+    frames = [rng.integers(0, 256, (H, W, 3), dtype=np.uint8) for _ in range(n)]
+    return VideoData(frames, (W, H), path), frames
+
+
+_FLAGS = [True] + [False] * 11 + [True] + [False] * 2 + [True, True] + [False] * 6      # 23 frames: segments of 11, 2, 0, 6
+
+
+def _pipeline_worker(rank, world, port, ws):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from sd_animation_optical_flow_amd.workspace import VideoData
+        video = VideoData(None, (24, 16), ws)
+        keys = _StubPipeline.make().run(video, _FLAGS)
+        torch.save(keys, os.path.join(ws, f"keys_r{rank}.pt"))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_gloo_pipeline_over_a_workspace(tmp_path):
+    """The rank-aware `ClipPipeline.run` over a `VideoData` workspace with world_size 2 (gloo): every frame rendered exactly
+    once, by the rank the plan names; the rendered key frame of the segment that had to be cut reaches the other rank through
+    the broadcast (its pixels enter every warped frame); the result equals the single-process run byte for byte."""
+    import numpy as np
+    from sd_animation_optical_flow_amd.workspace import VideoData
+    one, frames = _make_workspace(str(tmp_path / "one"))
+    keys1 = _StubPipeline.make().run(one, _FLAGS)
+    assert keys1 == [0, 12, 15, 16]
+    two, _ = _make_workspace(str(tmp_path / "two"))
+    world = 2
+    mp.spawn(_pipeline_worker, args=(world, _free_port(), str(tmp_path / "two")), nprocs=world, join=True)
+    plan = clip.plan_segments(_FLAGS, world)
+    assert any(p.needs_broadcast for p in plan)                                       # the 11-frame segment is cut (target 10)
+    keys = [torch.load(tmp_path / "two" / f"keys_r{r}.pt") for r in range(world)]
+    assert sorted(keys[0] + keys[1]) == keys1 and not set(keys[0]) & set(keys[1])     # each key frame rendered by ONE rank
+    for r in range(world):
+        assert keys[r] == [p.key for p in plan if p.owner == r]
+    a, b = VideoData(None, (24, 16), str(tmp_path / "one")), VideoData(None, (24, 16), str(tmp_path / "two"))
+    for i in range(len(_FLAGS)):
+        assert b.generated(i), i
+        assert np.array_equal(a.get_ai_frame(i), b.get_ai_frame(i)), i

@@ -54,6 +54,21 @@ def main():
         fb, wb = f * 1024.0 / n, w * 1024.0 / max(nw, 1)
         res[fam] = {"launches": n, "fetch_bytes_per_launch_raw": fb, "write_bytes_per_launch": wb,
                     "hbm_bytes_per_launch_corrected": 2.0 * fb + wb}
+    # what the profile was taken on: the round tag, the source revision (.build_rev, written by tools/profile_round.sh's caller
+    # before the snapshot leaves for the GPU box -- .git does not travel) and the sha256 of the libofx.so that ran
+    import hashlib
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    meta = {"tag": sys.argv[3] if len(sys.argv) > 3 else None, "git_rev": None, "libofx_sha256": None}
+    try:
+        meta["git_rev"] = open(os.path.join(root, ".build_rev")).read().strip()
+    except OSError:
+        pass
+    try:
+        meta["libofx_sha256"] = hashlib.sha256(open(os.path.join(root, "sd_animation_optical_flow_amd", "libofx.so"), "rb").read()).hexdigest()
+    except OSError:
+        pass
+    res["_profile"] = meta
     json.dump(res, sys.stdout, indent=1)
     print()
 

@@ -21,7 +21,7 @@ cd $R
 python tools/rocpd_summary.py $TR > $O/${TAG}_bench_b64_kernel_stats.txt
 python tools/rocpd_summary.py --pmc $PF > $O/${TAG}_bench_b64_pmc_fetch.txt
 python tools/rocpd_summary.py --pmc $PW > $O/${TAG}_bench_b64_pmc_write.txt
-python tools/pmc_traffic.py $PF $PW > $O/${TAG}_pmc_traffic_b64.json
+python tools/pmc_traffic.py $PF $PW $TAG > $O/${TAG}_pmc_traffic_b64.json
 rm -rf $O/${TAG}_trace $O/${TAG}_pmc_fetch $O/${TAG}_pmc_write
 head -12 $O/${TAG}_bench_b64_kernel_stats.txt
 cat $O/${TAG}_pmc_traffic_b64.json
