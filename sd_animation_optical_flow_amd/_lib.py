@@ -10,7 +10,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libofx.so")
+# OFX_LIB_PATH: a diagnostic build of the same library (e.g. tools/alt/libofx_exact_gates.so); the default is the in-tree one
+LIB_PATH = os.environ.get("OFX_LIB_PATH") or os.path.join(_HERE, "libofx.so")
 
 
 class OfxLibraryError(RuntimeError):
@@ -90,6 +91,7 @@ SIGNATURES = {
     "ofx_corr_slice_floats": (_i, [_i, _i]),
     "ofx_corr_volume": (_i, [_p, _p, C.POINTER(_p), _i, _i, _i, _i, _i, _p]),
     "ofx_corr_lookup": (_i, [C.POINTER(_p), _p, _p, _i, _i, _i, _i, _i, _i, _p]),
+    "ofx_corr_lookup_convc1": (_i, [C.POINTER(_p), _p, _p, _p, _p, _i, _i, _i, _i, _p]),
     "ofx_local_corr_fwd": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
     "ofx_local_corr_bwd": (_i, [_p] * 6 + [_i] * 8 + [_p]),
     "ofx_avgpool2_nhwc": (_i, [_p, _p, _i, _i, _i, _i, _p]),

@@ -141,7 +141,11 @@ __global__ __launch_bounds__(256, 2) void flow_head_kernel(const FlowHeadArgs a)
         const int x = x0 + j, y = y0 + oy;
         if (x < a.w_ && y < a.h) {
             const long m = (long)(row0 + oy) * a.w_ + x;
-            const float c1 = a.coords1[m * 2 + o] + r1 + a.bias[o];
+            // delta = conv + bias first, THEN coords1 + delta (raft.py:128-131).  (coords1 + conv) + bias rounds twice at the magnitude of
+            // the coordinate, and the second rounding is the same for every pixel of a binade (a constant added to multiples of one
+            // ulp): a coherent -frac(bias / ulp) * ulp per iteration that grew linearly to 2.7e-4 px after 20 iterations and the 8x
+            // upsample (profiles/r03_epe_curve.txt)
+            const float c1 = a.coords1[m * 2 + o] + (r1 + a.bias[o]);
             a.coords1[m * 2 + o] = c1;
             const float fl = c1 - (float)(o == 0 ? x : y);
             a.hx_flow[m * a.ldh + o] = fl;

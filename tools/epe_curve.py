@@ -18,7 +18,7 @@ ITS = (1, 2, 5, 10, 20)
 pairs = [int(x) for x in sys.argv[1:]] or [0, 31, 63]
 sd = RO.init_state_dict(0)
 sd64 = RO.to_float64(sd)
-eng = RaftEngine(sd)
+eng = RaftEngine(sd, precision=os.environ.get("OFX_EPE_PRECISION", "fp32"))   # OFX_LIB_PATH=tools/alt/libofx_exact_gates.so: libm gates
 frames, key, _, _ = bench.make_clip(64, bench.H, bench.W, torch.device("cuda"))
 kf = key.cpu().permute(2, 0, 1)[None].float()
 epe = lambda a, b: (a.double() - b.double()).pow(2).sum(-1).sqrt().mean().item()
@@ -39,6 +39,23 @@ for b in pairs:
     u64, u32 = up64[0].permute(1, 2, 0), up32[0].permute(1, 2, 0)
     lines.append(f"{b:>4} {'up20':>5} {epe(up[0].cpu(), u64):>12.3e} {epe(u32, u64):>12.3e} {epe(up[0].cpu(), u32):>12.3e} {u64.norm(dim=-1).mean().item():>11.3f}")
     # the batch the bench times (64 frames, large-grid tile schedules) for the same frame
+    # which stage drifts?  the same pair with the instance-norm statistics taken by their own f64 pass (not out of the conv epilogues)
+    up_s, lo_s = eng.forward(frames[b:b + 1], key, iters=20, want_low=True, separate_stats=True)
+    l64 = tr64["flow_low_at"][20][0].permute(1, 2, 0)
+    lines.append(f"{b:>4} {'sep20':>5} {epe(lo_s[0].cpu(), l64):>12.3e} {'':>12} {'':>12}   # statistics by the separate f64 pass, low-res flow after 20")
+    lines.append(f"{b:>4} {'sepup':>5} {epe(up_s[0].cpu(), u64):>12.3e}")
+    # stage errors after ONE iteration against f64: feature maps, context, first hidden state
+    eng.forward(frames[b:b + 1], key, iters=1)
+    h8, w8 = bench.H // 8, bench.W // 8
+    fm1 = eng.buffer("fmap1").cpu().reshape(1, h8, w8, 256).permute(0, 3, 1, 2)
+    hx = eng.buffer("hx").cpu().reshape(1, h8, w8, 384).permute(0, 3, 1, 2)
+    rel = lambda x, r: ((x.double() - r).abs().mean() / r.abs().mean()).item()
+    lines.append(f"#   pair {b} stage errors (mean |err| / mean |ref|, against f64): fmap1 HIP {rel(fm1, tr64['fmap1']):.2e} cpu32 {rel(tr32['fmap1'], tr64['fmap1']):.2e}; "
+                 f"inp HIP {rel(hx[:, 256:], tr64['inp']):.2e} cpu32 {rel(tr32['inp'], tr64['inp']):.2e}; "
+                 f"net(it 1) HIP {rel(hx[:, :128], tr64['net_it0']):.2e} cpu32 {rel(tr32['net_it0'], tr64['net_it0']):.2e}")
+    eng.forward(frames[b:b + 1], key, iters=1, separate_stats=True)
+    fm1s = eng.buffer("fmap1").cpu().reshape(1, h8, w8, 256).permute(0, 3, 1, 2)
+    lines.append(f"#   pair {b} fmap1 with separate statistics: HIP {rel(fm1s, tr64['fmap1']):.2e}")
 lines.append(f"# batch of 64 (the timed schedule), same frames:")
 fl = eng.forward(frames, key, iters=20)
 for b in pairs:
@@ -47,6 +64,6 @@ for b in pairs:
     lines.append(f"{b:>4} {'b64':>5} {epe(fl[b].cpu(), up64[0].permute(1, 2, 0)):>12.3e}")
 lines.append(f"# {time.time() - t0:.0f} s")
 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-with open(os.path.join(ROOT, "gpurun_out", "r03_epe_curve.txt"), "w") as f:
+with open(os.path.join(ROOT, "gpurun_out", os.environ.get("OFX_EPE_OUT", "r03_epe_curve.txt")), "w") as f:
     f.write("\n".join(lines) + "\n")
 print("\n".join(lines))
