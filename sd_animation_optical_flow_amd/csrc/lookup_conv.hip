@@ -21,10 +21,21 @@
 // persistent (two workgroups per CU walk the tiles), so a producer is already gathering the next tile's level 0 while
 // the consumers finish level 3 and store.
 //
-// Bound: the GEMM (2 * 336 * 256 flop per pixel on the fp32 MFMA), not HBM -- the gather's traffic hides under it.
+// Bound: the GEMM (2 * 336 * 256 flop per pixel on the fp32 MFMA: >= 430 us per 64-pair launch), not HBM -- fusing can only hide the
+// gather (265 us of HBM time) under it and drop the row's 1.02 GB round trip.
+//
+// MEASURED (tools/lookup_bench.py, B = 64 at 512x768): 906-1085 us against 886 us for the two kernels it replaces (lookup 355 +
+// convc1 530), results identical to 7e-7.  It does NOT win yet, so the RAFT executor keeps the two-kernel schedule by default
+// (OFX_RAFT_FUSED_LOOKUP / OFX_FUSED_LOOKUP=1 select this kernel).  Why, from the probes (each role idled in turn): the consumers alone
+// need 710-735 us = 89-92 TFLOP/s -- two MFMA-issuing waves per SIMD do not hide their own LDS / L2 latencies the way the convolution
+// kernel's four do (123 TFLOP/s on the same GEMM) -- and the producers alone need 620-690 us: the gather is instruction- and
+// LDS-latency-bound at eight producer waves per CU (87 VALU + 42 SALU + 8 LDS instructions per pixel-level), where the stand-alone
+// lookup kernel keeps 32 waves per CU in flight.  A variant without roles (every wave gathers, then multiplies; four workgroups per
+// CU) measured 1300 us.  The 128-register budget the accumulators impose is what caps the waves per CU in every variant.
 #include "ofx_internal.h"
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -55,95 +66,106 @@ struct LcArgs {
     int ntiles;
 };
 
-// ---- producer: level L of 16 pixels -> one A chunk ------------------------------------------------------------------
-template <int L>
-__device__ __forceinline__ void produce_level(const LcArgs& a, long m0, int pw, float* __restrict__ Achunk, float* __restrict__ win,
-                                              int lane) {
-    // per-lane constants of the block gather (corr.hip: 12 slots x 8 pieces of 16 B in two rounds) and of the 81 taps
-    const int part = lane & 7;
-    int bj[2], bi[2], lds_off[2];
+// ---- producer ------------------------------------------------------------------------------------------------------------
+// A wave's work on a tile is 64 items: (level 0..3) x (its 16 pixels).  The block loads of an item go out kDepth items ahead of the
+// item being blended -- across level chunks and across tiles, so the gather never restarts cold behind a barrier: HBM latency under
+// this access pattern is ~3 us and only the depth of that queue hides it.
+constexpr int kDepth = 4;            // items in flight per producer wave (2 x 16-byte loads each: 32 VGPRs); divides 64.  8 measured no faster
+constexpr int kItems = 4 * 16;
+
+struct ProdConst {                   // per-lane constants of the block gather (corr.hip: 12 slots x 8 pieces of 16 B in two rounds) and of the taps
+    int part, bj[2], bi[2], lds_off[2], tap_off[2];
     bool slot_ok[2];
+};
+
+__device__ __forceinline__ ProdConst prod_const(int lane) {
+    ProdConst c;
+    c.part = lane & 7;
 #pragma unroll
     for (int rr = 0; rr < 2; ++rr) {
         const int slot = rr * 8 + (lane >> 3);                  // slot = bj * 3 + bi, 12 used
-        slot_ok[rr] = slot < 12;
-        bj[rr] = (slot * 11) >> 5;
-        bi[rr] = slot - 3 * bj[rr];
-        lds_off[rr] = (bj[rr] * 4 + (part >> 1)) * kWinCols + bi[rr] * 8 + ((part & 1) << 2);
-    }
-    int tap_off[2];
-#pragma unroll
-    for (int rr = 0; rr < 2; ++rr) {
+        c.slot_ok[rr] = slot < 12;
+        c.bj[rr] = (slot * 11) >> 5;
+        c.bi[rr] = slot - 3 * c.bj[rr];
+        c.lds_off[rr] = (c.bj[rr] * 4 + (c.part >> 1)) * kWinCols + c.bi[rr] * 8 + ((c.part & 1) << 2);
         const int k = min(rr * 64 + lane, kTaps - 1);
         const int i = (k * 57) >> 9;                            // k / 9
-        tap_off[rr] = (k - 9 * i) * kWinCols + i;               // i: x offset (slow), j: y offset (fast)  (corr.py:37-43)
+        c.tap_off[rr] = (k - 9 * i) * kWinCols + i;             // i: x offset (slow), j: y offset (fast)  (corr.py:37-43)
     }
-    constexpr float inv = 1.0f / (float)(1 << L);               // exact: coords / 2**l
-    const int hb = a.hb[L], wb = a.wb[L];
-    const long slice = a.slice[L];
-    const float* __restrict__ base = a.pyr[L];
+    return c;
+}
 
-    constexpr int kDepth = 4;                                   // pixels whose block loads are in flight
-    v4i v[kDepth][2];
-    auto issue = [&](int p, int slot) __attribute__((always_inline)) {
-        const long m = min(m0 + pw + p, a.M - 1);
-        const unsigned m_lo = __builtin_amdgcn_readfirstlane((unsigned)m), m_hi = __builtin_amdgcn_readfirstlane((unsigned)(m >> 32));
-        const long mu = (long)(((unsigned long long)m_hi << 32) | m_lo);
-        const float2 c = reinterpret_cast<const float2*>(a.coords)[mu];
-        const float xs = c.x * inv, ys = c.y * inv;
-        const bool sane = fabsf(xs) < 1.0e7f && fabsf(ys) < 1.0e7f;
-        const int wx = sane ? (int)floorf(xs) - kR : -100000;
-        const int wy = sane ? (int)floorf(ys) - kR : -100000;
-        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(base + mu * slice), (short)0, (int)(slice * 4), 0x00020000);
+// coordinates of pixel p of the wave, from the lane-distributed copy (lane i holds pixel i % 16): scalar after the readlane
+__device__ __forceinline__ float2 pixel_coords(float2 cxy, int p) {
+    return make_float2(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(cxy.x), p)),
+                       __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cxy.y), p)));
+}
+
+// block loads of item (level l, pixel p) of the tile whose first pixel of this wave is m_w
+__device__ __forceinline__ void issue_item(const LcArgs& a, const ProdConst& pc, int l, int p, long m_w, float2 cxy, v4i (&v)[2]) {
+    const long m = min(m_w + p, a.M - 1);
+    const unsigned m_lo = __builtin_amdgcn_readfirstlane((unsigned)m), m_hi = __builtin_amdgcn_readfirstlane((unsigned)(m >> 32));
+    const long mu = (long)(((unsigned long long)m_hi << 32) | m_lo);
+    const float2 c = pixel_coords(cxy, p);
+    const float inv = 1.0f / (float)(1 << l);                   // exact: coords / 2**l
+    const float xs = c.x * inv, ys = c.y * inv;
+    const bool sane = fabsf(xs) < 1.0e7f && fabsf(ys) < 1.0e7f;
+    const int wx = sane ? (int)floorf(xs) - kR : -100000;
+    const int wy = sane ? (int)floorf(ys) - kR : -100000;
+    const int hb = a.hb[l], wb = a.wb[l];
+    const long slice = a.slice[l];
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(a.pyr[l] + mu * slice), (short)0, (int)(slice * 4), 0x00020000);
 #pragma unroll
-        for (int rr = 0; rr < 2; ++rr) {
-            const int by = (wy >> 2) + bj[rr], bx = (wx >> 3) + bi[rr];
-            const bool ok = slot_ok[rr] && (unsigned)by < (unsigned)hb && (unsigned)bx < (unsigned)wb;
-            const int voff = ((__mul24(by, wb) + bx) << 7) + (part << 4);
-            v[slot][rr] = __builtin_amdgcn_raw_buffer_load_b128(rs, ok ? voff : -1, 0, 0);   // out of range -> zeros
-        }
-    };
-#pragma unroll
-    for (int p = 0; p < kDepth; ++p) issue(p, p);
-#pragma unroll
-    for (int p = 0; p < 16; ++p) {
-        const int slot = p % kDepth;
-        // the pixel's window into this wave's LDS scratch
-#pragma unroll
-        for (int rr = 0; rr < 2; ++rr)
-            if (slot_ok[rr]) *reinterpret_cast<v4i*>(win + lds_off[rr]) = v[slot][rr];
-        if (p + kDepth < 16) issue(p + kDepth, slot);           // the registers are free again: next pixel's loads go out now
-        const long m = min(m0 + pw + p, a.M - 1);
-        const float2 c = reinterpret_cast<const float2*>(a.coords)[m];
-        const float xs = c.x * inv, ys = c.y * inv;
-        const bool sane = fabsf(xs) < 1.0e7f && fabsf(ys) < 1.0e7f;
-        const float xf = floorf(xs), yf = floorf(ys);
-        const float fx = xs - xf, fy = ys - yf;
-        const float w00 = (1.f - fx) * (1.f - fy), w01 = fx * (1.f - fy), w10 = (1.f - fx) * fy, w11 = fx * fy;
-        const int wx = sane ? (int)xf - kR : -100000, wy = sane ? (int)yf - kR : -100000;
-        // each wavefront owns its window: LDS operations of one wave complete in order
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        const float* sl = win + (wy & 3) * kWinCols + (wx & 7);
-        float* arow = Achunk + (pw + p) * kLDA;
-#pragma unroll
-        for (int rr = 0; rr < 2; ++rr) {
-            const float* b = sl + tap_off[rr];
-            const float v00 = b[0], v01 = b[1], v10 = b[kWinCols], v11 = b[kWinCols + 1];
-            float acc = v00 * w00;
-            acc = acc + v01 * w01;
-            acc = acc + v10 * w10;
-            acc = acc + v11 * w11;
-            if (rr == 0 || lane < kTaps - 64) arow[rr * 64 + lane] = acc;
-        }
-        __builtin_amdgcn_wave_barrier();                        // the window is rewritten by the next pixel
+    for (int rr = 0; rr < 2; ++rr) {
+        const int by = (wy >> 2) + pc.bj[rr], bx = (wx >> 3) + pc.bi[rr];
+        const bool ok = pc.slot_ok[rr] && (unsigned)by < (unsigned)hb && (unsigned)bx < (unsigned)wb;
+        const int voff = ((__mul24(by, wb) + bx) << 7) + (pc.part << 4);
+        v[rr] = __builtin_amdgcn_raw_buffer_load_b128(rs, ok ? voff : -1, 0, 0);   // out of range -> zeros
     }
+}
+
+// window of the item (in registers) -> this wave's LDS scratch -> 81 bilinear taps -> row p of the A chunk
+__device__ __forceinline__ void blend_item(const ProdConst& pc, int l, float2 c, const v4i (&v)[2], float* __restrict__ win,
+                                           float* __restrict__ arow, int lane) {
+#pragma unroll
+    for (int rr = 0; rr < 2; ++rr)
+        if (pc.slot_ok[rr]) *reinterpret_cast<v4i*>(win + pc.lds_off[rr]) = v[rr];
+    const float inv = 1.0f / (float)(1 << l);
+    const float xs = c.x * inv, ys = c.y * inv;
+    const bool sane = fabsf(xs) < 1.0e7f && fabsf(ys) < 1.0e7f;
+    const float xf = floorf(xs), yf = floorf(ys);
+    const float fx = xs - xf, fy = ys - yf;
+    const float w00 = (1.f - fx) * (1.f - fy), w01 = fx * (1.f - fy), w10 = (1.f - fx) * fy, w11 = fx * fy;
+    const int wx = sane ? (int)xf - kR : -100000, wy = sane ? (int)yf - kR : -100000;
+    // each wavefront owns its window: LDS operations of one wave complete in order
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const float* sl = win + (wy & 3) * kWinCols + (wx & 7);
+    float tv[2][4];
+#pragma unroll
+    for (int rr = 0; rr < 2; ++rr) {                            // all eight taps in flight together
+        const float* b = sl + pc.tap_off[rr];
+        tv[rr][0] = b[0]; tv[rr][1] = b[1]; tv[rr][2] = b[kWinCols]; tv[rr][3] = b[kWinCols + 1];
+    }
+    float ta[2];
+#pragma unroll
+    for (int rr = 0; rr < 2; ++rr) {
+        float acc = tv[rr][0] * w00;
+        acc = acc + tv[rr][1] * w01;
+        acc = acc + tv[rr][2] * w10;
+        acc = acc + tv[rr][3] * w11;
+        ta[rr] = acc;
+    }
+    arow[lane] = ta[0];
+    if (lane < kTaps - 64) arow[64 + lane] = ta[1];
+    __builtin_amdgcn_wave_barrier();                            // the window is rewritten by the next item
 }
 
 // ---- consumer: one level chunk (84 k) of a 64 x 64 output block per wave -----------------------------------------------
 // B fragments come from global memory in fragment order, prefetched two k-steps ahead into a ring of four register sets; a
-// tile has 4 x 11 = 44 steps, a multiple of four, so the ring position of every step is a compile-time constant.
+// tile has 4 x 11 = 44 steps, a multiple of four, so the ring position of every step is a compile-time constant.  A fragments are
+// read from LDS one k-step ahead of their MFMAs.
 struct BSet { float4 j0, j1; };
 
 template <int L>
@@ -168,37 +190,37 @@ __device__ __forceinline__ void consume_level(const float* __restrict__ Achunk, 
             dst.j1 = make_float4(__int_as_float(t1.x), __int_as_float(t1.y), 0.f, 0.f);
         }
     };
+    float4 fa[2][2];                                            // [step parity][row tile]
+#pragma unroll
+    for (int i = 0; i < 2; ++i) fa[0][i] = *reinterpret_cast<const float4*>(&Achunk[(i * 32 + frow) * kLDA + fk]);
 #pragma unroll
     for (int g = 0; g < kSteps; ++g) {
         constexpr int base = (L * kSteps) % 4;
         prefetch(g + 2, ring[(base + g + 2) % 4]);
         const BSet& b = ring[(base + g) % 4];
-        if (g < 10) {
-            float4 fa[2];
+        if (g + 1 < 10) {
 #pragma unroll
-            for (int i = 0; i < 2; ++i) fa[i] = *reinterpret_cast<const float4*>(&Achunk[(i * 32 + frow) * kLDA + g * 8 + fk]);
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].x, b.j0.x, acc[i][0], 0, 0, 0);
-                acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].y, b.j0.y, acc[i][0], 0, 0, 0);
-                acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].z, b.j0.z, acc[i][0], 0, 0, 0);
-                acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].w, b.j0.w, acc[i][0], 0, 0, 0);
-                acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].x, b.j1.x, acc[i][1], 0, 0, 0);
-                acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].y, b.j1.y, acc[i][1], 0, 0, 0);
-                acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].z, b.j1.z, acc[i][1], 0, 0, 0);
-                acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].w, b.j1.w, acc[i][1], 0, 0, 0);
-            }
-        } else {
+            for (int i = 0; i < 2; ++i) fa[(g + 1) & 1][i] = *reinterpret_cast<const float4*>(&Achunk[(i * 32 + frow) * kLDA + (g + 1) * 8 + fk]);
+        } else if (g + 1 == 10) {
             // the last four k of the level (80 = the 81st tap, 81..83 = zeros): lane half h supplies k = 80 + 2h + s
-            float2 fa[2];
-#pragma unroll
-            for (int i = 0; i < 2; ++i) fa[i] = *reinterpret_cast<const float2*>(&Achunk[(i * 32 + frow) * kLDA + 80 + (lane >> 5) * 2]);
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
-                acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].x, b.j0.x, acc[i][0], 0, 0, 0);
-                acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].y, b.j0.y, acc[i][0], 0, 0, 0);
-                acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].x, b.j1.x, acc[i][1], 0, 0, 0);
-                acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].y, b.j1.y, acc[i][1], 0, 0, 0);
+                const float2 t = *reinterpret_cast<const float2*>(&Achunk[(i * 32 + frow) * kLDA + 80 + (lane >> 5) * 2]);
+                fa[0][i] = make_float4(t.x, t.y, 0.f, 0.f);
+            }
+        }
+        const float4 (&f)[2] = fa[g & 1];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(f[i].x, b.j0.x, acc[i][0], 0, 0, 0);
+            acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(f[i].y, b.j0.y, acc[i][0], 0, 0, 0);
+            acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(f[i].x, b.j1.x, acc[i][1], 0, 0, 0);
+            acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(f[i].y, b.j1.y, acc[i][1], 0, 0, 0);
+            if (g < 10) {
+                acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(f[i].z, b.j0.z, acc[i][0], 0, 0, 0);
+                acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(f[i].w, b.j0.w, acc[i][0], 0, 0, 0);
+                acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(f[i].z, b.j1.z, acc[i][1], 0, 0, 0);
+                acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(f[i].w, b.j1.w, acc[i][1], 0, 0, 0);
             }
         }
     }
@@ -219,16 +241,30 @@ __global__ __launch_bounds__(512, 4) void lookup_convc1_kernel(const LcArgs a) {
         // ------------------------------------------------------------------ producers
         const int pw = (wave - 4) * 16;                        // this wave's 16 pixels of the tile
         float* w = win[wave - 4];
-        for (int t = blockIdx.x; t < a.ntiles; t += G) {
-            const long m0 = (long)t * kBM;
-            produce_level<0>(a, m0, pw, As[0], w, lane);
-            __syncthreads();
-            produce_level<1>(a, m0, pw, As[1], w, lane);
-            __syncthreads();
-            produce_level<2>(a, m0, pw, As[0], w, lane);
-            __syncthreads();
-            produce_level<3>(a, m0, pw, As[1], w, lane);
-            __syncthreads();
+        const ProdConst pc = prod_const(lane);
+        v4i v[kDepth][2];
+        int t = blockIdx.x;
+        if (t >= a.ntiles) return;                             // (the launcher never starts more workgroups than tiles)
+        long m_w = (long)t * kBM + pw;
+        // lane i holds the coordinates of pixel i % 16 of the wave (one load per tile, a tile ahead: a load per pixel would queue
+        // behind the block loads just issued -- vector-memory results return in order -- and serialise the pipeline)
+        float2 cxy = reinterpret_cast<const float2*>(a.coords)[min(m_w + (lane & 15), a.M - 1)];
+#pragma unroll
+        for (int q = 0; q < kDepth; ++q) issue_item(a, pc, q >> 4, q & 15, m_w, cxy, v[q]);
+        for (; t < a.ntiles; t += G) {
+            const long m_next = (long)min(t + G, a.ntiles - 1) * kBM + pw;      // past the last tile: harmless re-reads of the last one
+            const float2 cxy_next = reinterpret_cast<const float2*>(a.coords)[min(m_next + (lane & 15), a.M - 1)];
+#pragma unroll
+            for (int q = 0; q < kItems; ++q) {
+                const int l = q >> 4, p = q & 15;
+                blend_item(pc, l, pixel_coords(cxy, p), v[q % kDepth], w, &As[l & 1][(pw + p) * kLDA], lane);
+                const int qn = q + kDepth;                     // the registers are free again: the item kDepth ahead goes out now
+                if (qn < kItems) issue_item(a, pc, qn >> 4, qn & 15, m_w, cxy, v[q % kDepth]);
+                else issue_item(a, pc, (qn - kItems) >> 4, (qn - kItems) & 15, m_next, cxy_next, v[q % kDepth]);
+                if (p == 15) __syncthreads();                  // level chunk l is complete
+            }
+            m_w = m_next;
+            cxy = cxy_next;
         }
     } else {
         // ------------------------------------------------------------------ consumers
@@ -343,34 +379,28 @@ int ofx_lookup_conv_launch(const float* const* pyr, const float* coords, const f
         if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
             cus = prop.multiProcessorCount;
     }
-    const unsigned grid = (unsigned)std::min<long>(nt, 2L * cus);       // persistent: two workgroups per CU
     OfxProfScope prof("lookup_convc1", s);
     prof.flops(2.0 * (double)a.M * 336.0 * 256.0);
+    const unsigned grid = (unsigned)std::min<long>(nt, 2L * cus);       // persistent: two workgroups per CU
     hipLaunchKernelGGL(lookup_convc1_kernel, dim3(grid), dim3(512), 0, s, a);
     return ofx_launch_status();
 }
 
 extern "C" {
 
-// CorrBlock.__call__ + relu(convc1(.)) in one kernel.  pyr: the 4-level blocked pyramid of ofx_corr_volume; w: convc1's weight
-// [256][324] (OIHW with a 1x1 kernel); bias [256]; out [B*h*w][ldo >= 256].  Packs the weights on the host and uploads them for this
-// call (stream-ordered): the RAFT executor keeps a packed copy instead.
-int ofx_corr_lookup_convc1(const float* const* pyr, const float* coords, const float* w_host, const float* bias_dev, float* out, int ldo,
+// host side: convc1's weight [256][324] -> the fragment order the kernel streams (out: ofx_corr_lookup_convc1_pack_floats() floats)
+long ofx_corr_lookup_convc1_pack_floats(void) { return ofx_lookup_conv_pack_floats(); }
+int ofx_corr_lookup_convc1_pack(const float* w_host, float* out_host) {
+    OFX_REQUIRE(w_host && out_host, OFX_EINVAL);
+    return ofx_lookup_conv_pack(w_host, kLevels * kTaps, out_host);
+}
+
+// CorrBlock.__call__ + relu(convc1(.)) in one kernel.  pyr: the 4-level blocked pyramid of ofx_corr_volume; wf_dev: the packed
+// weights on the device; bias_dev [256]; out [B*h*w][ldo >= 256].
+int ofx_corr_lookup_convc1(const float* const* pyr, const float* coords, const float* wf_dev, const float* bias_dev, float* out, int ldo,
                            int B, int h, int w, void* stream) {
-    OFX_REQUIRE(pyr && coords && w_host && bias_dev && out, OFX_EINVAL);
-    hipStream_t s = (hipStream_t)stream;
-    std::vector<float> packed((size_t)ofx_lookup_conv_pack_floats());
-    int st = ofx_lookup_conv_pack(w_host, kLevels * kTaps, packed.data());
-    if (st) return st;
-    float* wf = nullptr;
-    OFX_HIP_CHECK(hipMallocAsync((void**)&wf, packed.size() * sizeof(float), s));
-    hipError_t e = hipMemcpyAsync(wf, packed.data(), packed.size() * sizeof(float), hipMemcpyHostToDevice, s);
-    if (e == hipSuccess) e = hipStreamSynchronize(s);          // `packed` is pageable host memory going out of scope
-    if (e == hipSuccess) st = ofx_lookup_conv_launch(pyr, coords, wf, bias_dev, out, ldo, B, h, w, s);
-    const hipError_t fe = hipFreeAsync(wf, s);
-    if (e != hipSuccess) return (int)e;
-    if (st) return st;
-    return fe == hipSuccess ? 0 : (int)fe;
+    OFX_REQUIRE(pyr && coords && wf_dev && bias_dev && out, OFX_EINVAL);
+    return ofx_lookup_conv_launch(pyr, coords, wf_dev, bias_dev, out, ldo, B, h, w, (hipStream_t)stream);
 }
 
 }  // extern "C"

@@ -553,7 +553,7 @@ static RaftWs carve(void* base, size_t cap, int B, int H, int W, int flags, int 
 // everything after the feature / context encoders and the correlation volume: state init, the loop-invariant
 // GRU terms, `iters` refinement iterations, mask head, convex upsample
 static int run_recurrence(ofx_raft* r, const RaftWs& ws, int B, int h, int w, int iters, bool alt, bool shared,
-                          float* flow_up, float* flow_low, hipStream_t s, int precision, bool overlap, bool unfused_lookup) {
+                          float* flow_up, float* flow_low, hipStream_t s, int precision, bool overlap, bool want_fused_lookup) {
     const long N = (long)h * w;
     const bool sh1 = shared, sh2 = shared;
     int st = 0;
@@ -581,11 +581,11 @@ static int run_recurrence(ofx_raft* r, const RaftWs& ws, int B, int h, int w, in
     auto C = [&](const char* k) -> const ConvW& { return r->convs[k]; };
     const float* pyr_c[LEVELS] = {ws.pyr[0], ws.pyr[1], ws.pyr[2], ws.pyr[3]};
     const int rd2 = (2 * RADIUS + 1) * (2 * RADIUS + 1);
-    // lookup + convc1 as ONE kernel (lookup_conv.hip): the 324-float correlation row per pixel stays in LDS.  fp32 arithmetic, the
-    // volume path, the reference's 4 levels x radius 4 only; OFX_RAFT_UNFUSED_LOOKUP / OFX_NO_FUSED_LOOKUP=1 keep the two kernels
-    // (and the `corr` buffer the stage tests read).
-    static const bool env_unfused = getenv("OFX_NO_FUSED_LOOKUP") != nullptr;
-    const bool fused_lookup = !alt && !unfused_lookup && !env_unfused && precision == OFX_PREC_FP32 && r->convc1_frag != nullptr &&
+    // lookup + convc1 as ONE kernel (lookup_conv.hip: the 324-float correlation row per pixel stays in LDS) -- opt-in through
+    // OFX_RAFT_FUSED_LOOKUP / OFX_FUSED_LOOKUP=1: parity-green but measured slower than the two kernels it replaces (see the header of
+    // lookup_conv.hip).  fp32 arithmetic, the volume path, the reference's 4 levels x radius 4 only.
+    static const bool env_fused = getenv("OFX_FUSED_LOOKUP") != nullptr;
+    const bool fused_lookup = !alt && (want_fused_lookup || env_fused) && precision == OFX_PREC_FP32 && r->convc1_frag != nullptr &&
                               ofx_lookup_conv_ok(h, w);
     for (int it = 0; it < iters && !L.st; ++it) {
         // flow features (update.py:93-94) on the side stream, from the flow the previous iteration left
@@ -817,7 +817,7 @@ int ofx_raft_forward(ofx_raft* r, const uint8_t* image1, const uint8_t* image2, 
         if (st) return st;
     }
 
-    st = run_recurrence(r, ws, B, h, w, iters, alt, sh1 || sh2, flow_up, flow_low, s, prec, overlap, flags & OFX_RAFT_UNFUSED_LOOKUP);
+    st = run_recurrence(r, ws, B, h, w, iters, alt, sh1 || sh2, flow_up, flow_low, s, prec, overlap, flags & OFX_RAFT_FUSED_LOOKUP);
     if (st) return st;
 
     r->bufs.clear();
@@ -911,7 +911,7 @@ int ofx_raft_forward_pairs(ofx_raft* r, const uint8_t* images, int n_images, con
     }
     if (!st) st = ofx_corr_pool_launch(ws.pyr[0], ws.pyr[1], ws.pyr[2], ws.pyr[3], B, h, w, LEVELS, s, fused_pairs);
     if (st) return st;
-    st = run_recurrence(r, ws, B, h, w, iters, false, false, flow_up, flow_low, s, prec, overlap, flags & OFX_RAFT_UNFUSED_LOOKUP);
+    st = run_recurrence(r, ws, B, h, w, iters, false, false, flow_up, flow_low, s, prec, overlap, flags & OFX_RAFT_FUSED_LOOKUP);
     if (st) return st;
     r->bufs.clear();
     return 0;
