@@ -92,6 +92,9 @@ def algorithmic_work(H, W, B, shared_key=True):
         "lookup_bytes": B * n * (400 * 4.0 + 324 * 4.0 + 8.0),                                          # per launch
         "upsample_bytes": B * (n * 576 * 4.0 + n * 8.0 + H * W * 8.0),
         "warp_bytes": B * (H * W * 8.0 + H * W * 3.0) + H * W * 3.0,
+        # upsample with the warp inside (one kernel): mask logits + coords in, flow_up + warped out, the key frame once -- the union of
+        # the two kernels' algorithmic bytes minus the flow re-read that no longer happens
+        "upsample_warp_bytes": B * (n * 576 * 4.0 + n * 8.0 + H * W * 8.0 + H * W * 3.0) + H * W * 3.0,
         "mask_bytes": B * (H * W * 4.0 + H * W * 1.0),
     }
 
@@ -283,6 +286,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch", type=int, default=64, help="frames per GPU per step")
     ap.add_argument("--warp-mode", default="bilinear", choices=["bilinear", "bicubic", "cv2_cubic"])
+    ap.add_argument("--separate-warp", action="store_true", help="upsample and warp as two kernels (default: the warp runs inside the convex upsample)")
     ap.add_argument("--no-prof", action="store_true", help="do not bracket launches with HIP events")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true", help="skip the oracle check of one sampled pair")
@@ -349,8 +353,14 @@ def main():
 
         def step():
             clip.broadcast_keyframe([key, key_ai], src=0)                 # the path's only exchange
-            flow = eng.forward(frames, key, iters=ITERS)                  # frame -> key frame, shared image2
-            warped, mask = ops.warp_and_mask(key_ai, flow, conf, warp_mode=args.warp_mode, thres=0.95, ksize=7)
+            if args.warp_mode == "bilinear" and not args.separate_warp:
+                # frame -> key frame, shared image2; the AI key frame is warped inside the convex upsample (one kernel instead of
+                # upsample + warp, same bytes out: flow, warped); then the confidence-threshold mask
+                flow, warped = eng.forward(frames, key, iters=ITERS, warp_frame=key_ai)
+                mask = ops.generate_mask(conf, None, 0.95, 7)
+            else:
+                flow = eng.forward(frames, key, iters=ITERS)
+                warped, mask = ops.warp_and_mask(key_ai, flow, conf, warp_mode=args.warp_mode, thres=0.95, ksize=7)
             return flow, warped, mask
 
     def barrier():
@@ -462,6 +472,7 @@ def main():
         hbm("corr_lookup", "lookup_total", "corr_lookup")
         hbm("upsample_flow", "upsample_bytes", "upsample_flow")
         hbm("warp_u8", "warp_bytes", "warp")
+        hbm("upsample_warp", "upsample_warp_bytes", "upsample_warp")
         hbm("generate_mask", "mask_bytes", "mask")
         m, c = per_launch(["igemm_corr_volume"])
         if c:
@@ -493,7 +504,7 @@ def main():
                 out["roofline"]["traffic_source"] = src
             for label, tkey in (("corr_volume_gemm", "corr_volume_gemm"), ("corr_lookup", "corr_lookup"),
                                ("corr_pyramid_pool", "pyramid_pool"), ("upsample_flow", "upsample"),
-                               ("warp", "warp"), ("mask", "mask")):
+                               ("warp", "warp"), ("mask", "mask"), ("upsample_warp", "upsample_warp")):
                 if label in ks and tkey in tr:
                     ks[label]["traffic"] = tr[tkey]["hbm_bytes_per_launch_corrected"]
                     ks[label]["traffic_source"] = "profile"

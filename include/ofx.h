@@ -288,6 +288,12 @@ int ofx_avgpool2_nhwc(const float* in, float* out, int B, int H, int W, int C, v
 /* convex 8x upsample: coords1 [B*h*w][2], mask [B*h*w][576] -> flow_up f32[B, 8h, 8w, 2] */
 int ofx_upsample_flow(const float* coords1, const float* mask, float* flow_up, int B, int h, int w,
                       void* stream);
+/* ofx_upsample_flow + the bilinear backward warp of one shared frame u8 [8h][8w][3] in ONE kernel (the flow of a lane's four fine
+ * pixels is sampled while it is still in registers): warped u8 [B][8h][8w][3]; flow_up f32 [B][8h][8w][2] or NULL (not written).
+ * sign = +1 (PDCNet convention, pdcnet_of.py:34-42) or -1 (RAFT convention, ofgen_keyframe_inpaint.py:92-98).
+ * Bit-identical to ofx_upsample_flow followed by ofx_warp_u8(OFX_WARP_BILINEAR) with frame_batch_stride = 0. */
+int ofx_upsample_flow_warp(const float* coords1, const float* mask, float* flow_up, const uint8_t* frame,
+                           uint8_t* warped, int B, int h, int w, float sign, void* stream);
 
 /* ---------------------------------------------------------------- RAFT engine */
 typedef struct ofx_tensor {            /* one entry of a checkpoint state_dict (host memory, fp32) */
@@ -327,6 +333,14 @@ size_t ofx_raft_workspace_bytes(const ofx_raft* r, int B, int H, int W);
 int ofx_raft_forward(ofx_raft* r, const uint8_t* image1, const uint8_t* image2, int B, int H, int W,
                      int iters, int flags, float* flow_up, float* flow_low, void* workspace,
                      size_t workspace_bytes, void* stream);
+/* The same forward with the backward warp of ONE shared uint8 RGB frame (the rendered AI key frame) done inside the convex
+ * upsample -- the tail of the hot path (pdcnet_of.py:34-42 in its bilinear mode; warp_sign = +1: out(y,x) = frame(y + fy, x + fx),
+ * -1: the RAFT-side convention of ofgen_keyframe_inpaint.py:92-98): warped u8 [B,H,W,3] = the bilinear warp of warp_frame u8 [H,W,3]
+ * along the final flow, bit-identical to ofx_raft_forward followed by ofx_warp_u8(bilinear).  flow_up may be NULL (then the full-
+ * resolution flow is never written: 201 MB less traffic per 64 frames at 512x768). */
+int ofx_raft_forward_warp(ofx_raft* r, const uint8_t* image1, const uint8_t* image2, int B, int H, int W,
+                          int iters, int flags, float* flow_up, float* flow_low, const uint8_t* warp_frame,
+                          float warp_sign, uint8_t* warped, void* workspace, size_t workspace_bytes, void* stream);
 /* Indexed pairs ("next" row f1, KeyframeConv / calculate_pairwise, ofgen_keyframe_inpaint.py:627-668):
  * n_images unique uint8 frames [n,H,W,3] on the device and B pairs (idx1[b], idx2[b]) given as HOST int
  * arrays; flow b is defined on image idx1[b] and points into image idx2[b].  Every image is encoded once

@@ -98,10 +98,12 @@ SIGNATURES = {
     "ofx_local_corr_bwd": (_i, [_p] * 6 + [_i] * 8 + [_p]),
     "ofx_avgpool2_nhwc": (_i, [_p, _p, _i, _i, _i, _i, _p]),
     "ofx_upsample_flow": (_i, [_p, _p, _p, _i, _i, _i, _p]),
+    "ofx_upsample_flow_warp": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _f, _p]),
     "ofx_raft_create": (_i, [C.POINTER(Tensor), _i, C.POINTER(_p)]),
     "ofx_raft_destroy": (_i, [_p]),
     "ofx_raft_workspace_bytes": (_z, [_p, _i, _i, _i]),
     "ofx_raft_forward": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p, _p, _p, _z, _p]),
+    "ofx_raft_forward_warp": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p, _p, _p, _f, _p, _p, _z, _p]),
     "ofx_raft_workspace_bytes_pairs": (_z, [_p, _i, _i, _i, _i]),
     "ofx_raft_forward_pairs": (_i, [_p, _p, _i, C.POINTER(_i), C.POINTER(_i), _i, _i, _i, _i, _i, _p, _p, _p, _z, _p]),
     "ofx_raft_buffer": (_i, [_p, C.c_char_p, C.POINTER(_p), C.POINTER(_z)]),

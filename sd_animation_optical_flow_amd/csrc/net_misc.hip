@@ -7,6 +7,7 @@
 //   residual merge  RAFT/core/extractor.py:46-56
 //   convex upsample RAFT/core/raft.py:72-83
 #include "ofx_internal.h"
+#include "upsample_inl.h"
 
 namespace {
 
@@ -183,64 +184,11 @@ __global__ __launch_bounds__(256) void inorm_apply_kernel(const float* __restric
     }
 }
 
-// ---- convex upsample: one wavefront per FOUR horizontally adjacent coarse pixels; lane = (pixel p, quad q):
-// sub-pixels (i, j..j+3) with i = q >> 1, j = (q & 1) * 4.  The 9 x 64 mask logits of a pixel are read as 16-byte
-// loads (4x fewer load instructions than a lane per sub-pixel) and the 4 results leave as two 16-byte stores; the
-// two lanes of a row and the four pixels of the wave make 128-byte output runs.
+// ---- convex upsample (the per-lane arithmetic lives in upsample_inl.h, shared with the upsample + warp kernel of warp_fast.hip)
 __global__ __launch_bounds__(256) void upsample_kernel(const float* __restrict__ coords1, const float* __restrict__ mask,
                                                        float* __restrict__ flow_up, int h, int w, long M) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int wq = (w + 3) >> 2;                                   // groups of 4 pixels per coarse row
-    const long grp = (long)blockIdx.x * 4 + wave;
-    const long rows = M / w;                                       // B * h
-    if (grp >= rows * wq) return;
-    const long row = grp / wq;                                     // b*h + y
-    const int xg = (int)(grp - row * wq);
-    const int p = lane >> 4, q = lane & 15;
-    const int x = xg * 4 + p;
-    if (x >= w) return;
-    const int y = (int)(row % h);
-    const long b = row / h;
-    const long m = row * w + x;
-    const float* mk = mask + m * 576 + q * 4;
-    float4 lg[9];
-#pragma unroll
-    for (int k = 0; k < 9; ++k) lg[k] = *reinterpret_cast<const float4*>(mk + k * 64);
-    float4 mx = lg[0];
-#pragma unroll
-    for (int k = 1; k < 9; ++k) {
-        mx.x = fmaxf(mx.x, lg[k].x); mx.y = fmaxf(mx.y, lg[k].y); mx.z = fmaxf(mx.z, lg[k].z); mx.w = fmaxf(mx.w, lg[k].w);
-    }
-    float4 den = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-    for (int k = 0; k < 9; ++k) {
-        // v_exp_f32 path (~2 ulp): 576 exponentials per coarse pixel made the libm version VALU-bound
-        lg[k].x = __expf(lg[k].x - mx.x); lg[k].y = __expf(lg[k].y - mx.y);
-        lg[k].z = __expf(lg[k].z - mx.z); lg[k].w = __expf(lg[k].w - mx.w);
-        den.x += lg[k].x; den.y += lg[k].y; den.z += lg[k].z; den.w += lg[k].w;
-    }
-    const float4 inv = make_float4(__builtin_amdgcn_rcpf(den.x), __builtin_amdgcn_rcpf(den.y), __builtin_amdgcn_rcpf(den.z),
-                                   __builtin_amdgcn_rcpf(den.w));
-    float4 ax = make_float4(0.f, 0.f, 0.f, 0.f), ay = ax;
-    const long hw = (long)h * w;
-#pragma unroll
-    for (int k = 0; k < 9; ++k) {
-        const int yy = y + k / 3 - 1, xx = x + k % 3 - 1;
-        float fx = 0.f, fy = 0.f;
-        if ((unsigned)yy < (unsigned)h && (unsigned)xx < (unsigned)w) {
-            const float2 c = reinterpret_cast<const float2*>(coords1)[b * hw + (long)yy * w + xx];
-            fx = 8.0f * (c.x - (float)xx);    // 8 * (coords1 - coords0)
-            fy = 8.0f * (c.y - (float)yy);
-        }
-        const float4 wgt = make_float4(lg[k].x * inv.x, lg[k].y * inv.y, lg[k].z * inv.z, lg[k].w * inv.w);
-        ax.x += wgt.x * fx; ax.y += wgt.y * fx; ax.z += wgt.z * fx; ax.w += wgt.w * fx;
-        ay.x += wgt.x * fy; ay.y += wgt.y * fy; ay.z += wgt.z * fy; ay.w += wgt.w * fy;
-    }
-    const int i = q >> 1, j = (q & 1) * 4;
-    const long W8 = (long)w * 8;
-    float4* o = reinterpret_cast<float4*>(flow_up + 2 * ((b * h * 8 + (long)y * 8 + i) * W8 + (long)x * 8 + j));
-    o[0] = make_float4(ax.x, ay.x, ax.y, ay.y);
-    o[1] = make_float4(ax.z, ay.z, ax.w, ay.w);
+    const OfxUpLane o = ofx_upsample_lane(coords1, mask, h, w, M);
+    if (o.valid) ofx_upsample_store(o, flow_up, h, w);
 }
 
 // coords1 = pixel grid, flow4 = 0, hx[:, flow_off:flow_off+2] = 0   (RAFT.initialize_flow, raft.py:63-70)

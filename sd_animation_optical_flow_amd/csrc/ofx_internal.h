@@ -81,6 +81,12 @@ int ofx_mask_bits_launch(int src, const float* conf, float* log_conf, const uint
 // warp_fast.hip: bilinear warp of one shared uint8 RGB key frame (0 = launched, OFX_EINVAL = shape not taken)
 int ofx_warp_bilinear_shared_launch(const uint8_t* frame, const float* flow, uint8_t* out, int B, int H, int W, float sign,
                                     hipStream_t s);
+// warp_fast.hip: convex upsample + bilinear warp of one shared key frame in one pass (pad = zero-bordered RGBX copy of the frame)
+size_t ofx_warp_pad_bytes(int H, int W);
+bool ofx_upsample_warp_ok(int B, int H, int W);
+int ofx_warp_pad_launch(const uint8_t* frame, void* pad, int H, int W, hipStream_t s);
+int ofx_upsample_warp_launch(const float* coords1, const float* mask, float* flow_up, const void* pad, uint8_t* warped, int B, int h, int w,
+                             float sign, hipStream_t s);
 int ofx_init_state(float* coords1, float* flow4, float* hx, int ldh, int flow_off, int B, int h, int w, hipStream_t s);
 int ofx_coords_to_flow(const float* coords1, float* flow, int B, int h, int w, hipStream_t s);
 int ofx_flow_head_launch(const float* x, int ldx, const float* w, int Kpad, const float* bias, float* coords1, float* hx_flow,

@@ -485,6 +485,7 @@ struct RaftWs {
     int* idx_dev;     // indexed-pairs mode: image1 index per pair
     float* pyr[LEVELS];
     float *hx, *gadd, *coords1, *flow4, *corr, *c1, *corflo, *f1, *z, *rh, *mask;
+    void* warp_pad;   // zero-bordered RGBX copy of the frame the tail warps (ofx_raft_forward_warp)
     size_t bytes;
 };
 
@@ -546,6 +547,7 @@ static RaftWs carve(void* base, size_t cap, int B, int H, int W, int flags, int 
     w.z = c.take((size_t)M * HD);
     w.rh = c.take((size_t)M * HD);
     w.mask = c.take((size_t)M * 576);
+    w.warp_pad = c.take(ofx_warp_pad_bytes(H, W) / sizeof(float) + 4);
     w.bytes = c.off;
     return w;
 }
@@ -553,7 +555,8 @@ static RaftWs carve(void* base, size_t cap, int B, int H, int W, int flags, int 
 // everything after the feature / context encoders and the correlation volume: state init, the loop-invariant
 // GRU terms, `iters` refinement iterations, mask head, convex upsample
 static int run_recurrence(ofx_raft* r, const RaftWs& ws, int B, int h, int w, int iters, bool alt, bool shared,
-                          float* flow_up, float* flow_low, hipStream_t s, int precision, bool overlap, bool want_fused_lookup) {
+                          float* flow_up, float* flow_low, hipStream_t s, int precision, bool overlap, bool want_fused_lookup,
+                          uint8_t* warped = nullptr, float warp_sign = 1.0f) {
     const long N = (long)h * w;
     const bool sh1 = shared, sh2 = shared;
     int st = 0;
@@ -637,7 +640,10 @@ static int run_recurrence(ofx_raft* r, const RaftWs& ws, int B, int h, int w, in
     L.conv(C("mask0"), ws.hx, HX_LD, HD, nullptr, 0, 0, ws.c1, 256, B, h, w, 1, OFX_ACT_RELU);
     L.conv(C("mask2"), ws.c1, 256, 256, nullptr, 0, 0, ws.mask, 576, B, h, w, 1, OFX_ACT_NONE);
     if (L.st) return L.st;
-    st = ofx_upsample_flow(ws.coords1, ws.mask, flow_up, B, h, w, s);
+    // convex upsample -- with the backward warp of the AI key frame in the same pass when the caller asked for it: the flow is in
+    // registers right there, flow_up is then written only if wanted
+    if (warped) st = ofx_upsample_warp_launch(ws.coords1, ws.mask, flow_up, ws.warp_pad, warped, B, h, w, warp_sign, s);
+    else st = ofx_upsample_flow(ws.coords1, ws.mask, flow_up, B, h, w, s);
     if (st) return st;
     if (flow_low) {
         st = ofx_coords_to_flow(ws.coords1, flow_low, B, h, w, s);
@@ -646,6 +652,10 @@ static int run_recurrence(ofx_raft* r, const RaftWs& ws, int B, int h, int w, in
 
     return 0;
 }
+
+static int raft_forward_impl(ofx_raft* r, const uint8_t* image1, const uint8_t* image2, int B, int H, int W, int iters, int flags,
+                             float* flow_up, float* flow_low, const uint8_t* warp_frame, float warp_sign, uint8_t* warped, void* workspace,
+                             size_t workspace_bytes, void* stream);
 
 extern "C" {
 
@@ -724,7 +734,25 @@ size_t ofx_raft_workspace_bytes(const ofx_raft* r, int B, int H, int W) {
 
 int ofx_raft_forward(ofx_raft* r, const uint8_t* image1, const uint8_t* image2, int B, int H, int W, int iters,
                      int flags, float* flow_up, float* flow_low, void* workspace, size_t workspace_bytes, void* stream) {
-    OFX_REQUIRE(r && image1 && image2 && flow_up && workspace, OFX_EINVAL);
+    OFX_REQUIRE(flow_up, OFX_EINVAL);
+    return raft_forward_impl(r, image1, image2, B, H, W, iters, flags, flow_up, flow_low, nullptr, 1.0f, nullptr, workspace, workspace_bytes, stream);
+}
+
+int ofx_raft_forward_warp(ofx_raft* r, const uint8_t* image1, const uint8_t* image2, int B, int H, int W, int iters, int flags,
+                          float* flow_up, float* flow_low, const uint8_t* warp_frame, float warp_sign, uint8_t* warped, void* workspace,
+                          size_t workspace_bytes, void* stream) {
+    OFX_REQUIRE(warp_frame && warped && (warp_sign == 1.0f || warp_sign == -1.0f), OFX_EINVAL);
+    OFX_REQUIRE(ofx_upsample_warp_ok(B, H, W) && (((uintptr_t)warped) & 3u) == 0, OFX_EINVAL);
+    return raft_forward_impl(r, image1, image2, B, H, W, iters, flags, flow_up, flow_low, warp_frame, warp_sign, warped, workspace, workspace_bytes,
+                             stream);
+}
+
+}  // extern "C"
+
+static int raft_forward_impl(ofx_raft* r, const uint8_t* image1, const uint8_t* image2, int B, int H, int W, int iters, int flags,
+                             float* flow_up, float* flow_low, const uint8_t* warp_frame, float warp_sign, uint8_t* warped, void* workspace,
+                             size_t workspace_bytes, void* stream) {
+    OFX_REQUIRE(r && image1 && image2 && (flow_up || warped) && workspace, OFX_EINVAL);
     OFX_REQUIRE(B > 0 && H >= 64 && W >= 64 && (H % 8) == 0 && (W % 8) == 0 && iters >= 1, OFX_EINVAL);
     OFX_REQUIRE((((uintptr_t)workspace) & 255u) == 0, OFX_EALIGN);
     RaftWs ws = carve(workspace, workspace_bytes, B, H, W, flags);
@@ -817,7 +845,12 @@ int ofx_raft_forward(ofx_raft* r, const uint8_t* image1, const uint8_t* image2, 
         if (st) return st;
     }
 
-    st = run_recurrence(r, ws, B, h, w, iters, alt, sh1 || sh2, flow_up, flow_low, s, prec, overlap, flags & OFX_RAFT_FUSED_LOOKUP);
+    if (warped) {   // the zero-bordered RGBX copy the warp samples (1.6 MB at 512x768: stays in L2)
+        st = ofx_warp_pad_launch(warp_frame, ws.warp_pad, H, W, s);
+        if (st) return st;
+    }
+    st = run_recurrence(r, ws, B, h, w, iters, alt, sh1 || sh2, flow_up, flow_low, s, prec, overlap, flags & OFX_RAFT_FUSED_LOOKUP, warped,
+                        warp_sign);
     if (st) return st;
 
     r->bufs.clear();
@@ -836,6 +869,8 @@ int ofx_raft_forward(ofx_raft* r, const uint8_t* image1, const uint8_t* image2, 
         }
     return 0;
 }
+
+extern "C" {
 
 size_t ofx_raft_workspace_bytes_pairs(const ofx_raft* r, int n_images, int B, int H, int W) {
     (void)r;

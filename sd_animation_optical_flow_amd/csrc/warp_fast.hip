@@ -21,6 +21,7 @@
 // This file is compiled with FMA contraction ON (u8 results may differ from the weights-form oracle by 1 LSB on
 // rounding ties only; the tests bound that).
 #include "ofx_internal.h"
+#include "upsample_inl.h"
 
 namespace {
 
@@ -123,7 +124,75 @@ __global__ __launch_bounds__(256) void warp_bilinear_shared_kernel(const FastArg
     warp_group(a, row, x, y, fa, fb);
 }
 
+// ---- convex upsample + warp in one pass: the flow of a lane's four fine pixels is still in registers when the upsample ends, so the
+// AI key frame is sampled right there -- the 201 MB re-read of flow_up (64 frames at 512x768) and one of the warp's three dependent
+// round trips disappear; flow_up itself is written only when the caller wants it.  Same arithmetic as upsample_kernel followed by
+// warp_bilinear_shared_kernel (the two device functions are shared), so the results are bit-identical.
+__global__ __launch_bounds__(256) void upsample_warp_kernel(const float* __restrict__ coords1, const float* __restrict__ mask,
+                                                            float* __restrict__ flow_up, const FastArgs a, int h, int w, long M) {
+    const OfxUpLane o = ofx_upsample_lane(coords1, mask, h, w, M);
+    if (!o.valid) return;
+    if (flow_up) ofx_upsample_store(o, flow_up, h, w);
+    const int X = o.x * 8 + o.j, Y = o.y * 8 + o.i;
+    const unsigned row = (unsigned)(o.b * a.H + Y);
+    warp_group(a, row, X, Y, make_float4(o.ax.x, o.ay.x, o.ax.y, o.ay.y), make_float4(o.ax.z, o.ay.z, o.ax.w, o.ay.w));
+}
+
 }  // namespace
+
+// zero-bordered RGBX copy of a key frame for the bilinear warp: `pad` holds (H + 4) * (W + 4) uint32
+size_t ofx_warp_pad_bytes(int H, int W) { return (size_t)(W + 2 * kPad) * (H + 2 * kPad) * sizeof(uint32_t); }
+bool ofx_upsample_warp_ok(int B, int H, int W) {
+    return (W & 7) == 0 && (H & 7) == 0 && H >= 8 && (long)B * H * W * 3 < (1L << 40) && H + 2 * kPad < (1 << 15) && W + 2 * kPad < (1 << 15) &&
+           (long)B * H < (1L << 31);
+}
+int ofx_warp_pad_launch(const uint8_t* frame, void* pad, int H, int W, hipStream_t s) {
+    const int Wp = W + 2 * kPad, Hp = H + 2 * kPad;
+    PadArgs pa{frame, (uint32_t*)pad, H, W, Wp, (unsigned)(Wp * Hp)};
+    OfxProfScope prof("warp_pad_keyframe", s);
+    hipLaunchKernelGGL(pad_rgbx_kernel, dim3(ofx_cdiv(pa.total, 256)), dim3(256), 0, s, pa);
+    return ofx_launch_status();
+}
+// coords1 [B*h*w][2], mask [B*h*w][576] -> warped u8 [B, 8h, 8w, 3] (and flow_up f32 [B, 8h, 8w, 2] unless NULL); `pad` from ofx_warp_pad_launch
+int ofx_upsample_warp_launch(const float* coords1, const float* mask, float* flow_up, const void* pad, uint8_t* warped, int B, int h, int w,
+                             float sign, hipStream_t s) {
+    const int H = h * 8, W = w * 8;
+    OFX_REQUIRE(coords1 && mask && pad && warped && ofx_upsample_warp_ok(B, H, W), OFX_EINVAL);
+    OFX_REQUIRE((((uintptr_t)coords1) & 7u) == 0 && ofx_aligned16(mask) && (!flow_up || ofx_aligned16(flow_up)) && (((uintptr_t)warped) & 3u) == 0,
+                OFX_EALIGN);
+    const int Wp = W + 2 * kPad;
+    FastArgs a;
+    a.pad = (const uint32_t*)pad + (size_t)kPad * Wp + kPad;
+    a.flow = nullptr; a.out = warped;
+    a.H = H; a.W = W; a.Wp = Wp;
+    a.sign = sign;
+    const long M = (long)B * h * w;
+    const long groups = (M / w) * ((w + 3) / 4);               // 4 coarse pixels per wavefront, 4 wavefronts per workgroup
+    OfxProfScope prof("upsample_warp", s);
+    hipLaunchKernelGGL(upsample_warp_kernel, dim3((unsigned)((groups + 3) / 4)), dim3(256), 0, s, coords1, mask, flow_up, a, h, w, M);
+    return ofx_launch_status();
+}
+
+extern "C" {
+
+// RAFT.upsample_flow (raft.py:72-83) + the bilinear backward warp of ONE shared uint8 RGB frame (pdcnet_of.py:34-42 in its bilinear
+// mode; sign = +1: out(y,x) = frame(y + fy, x + fx), -1: the RAFT-side convention of ofgen_keyframe_inpaint.py:92-98) in one kernel.
+// coords1 [B*h*w][2] and mask [B*h*w][576] as ofx_upsample_flow takes them; frame u8 [8h][8w][3]; warped u8 [B][8h][8w][3];
+// flow_up f32 [B][8h][8w][2] or NULL (not written).  Bit-identical to ofx_upsample_flow followed by ofx_warp_u8(bilinear).
+int ofx_upsample_flow_warp(const float* coords1, const float* mask, float* flow_up, const uint8_t* frame, uint8_t* warped, int B, int h, int w,
+                           float sign, void* stream) {
+    OFX_REQUIRE(coords1 && mask && frame && warped && B > 0 && h > 0 && w > 0, OFX_EINVAL);
+    OFX_REQUIRE(ofx_upsample_warp_ok(B, h * 8, w * 8), OFX_EINVAL);
+    hipStream_t s = (hipStream_t)stream;
+    void* pad = nullptr;
+    OFX_HIP_CHECK(hipMallocAsync(&pad, ofx_warp_pad_bytes(h * 8, w * 8), s));
+    int st = ofx_warp_pad_launch(frame, pad, h * 8, w * 8, s);
+    if (!st) st = ofx_upsample_warp_launch(coords1, mask, flow_up, pad, warped, B, h, w, sign, s);
+    const hipError_t e = hipFreeAsync(pad, s);
+    return st ? st : (int)e;
+}
+
+}  // extern "C"
 
 // Returns 0 when the launch was taken, OFX_EINVAL when the shape is outside this path's limits (the caller then uses
 // the generic kernels), or a HIP error.  The padded key frame is a stream-ordered allocation (hipMallocAsync /

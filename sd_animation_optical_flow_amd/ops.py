@@ -342,6 +342,22 @@ def corr_unblock(p: torch.Tensor, hl: int, wl: int) -> torch.Tensor:
     return q[:, :hl, :wl].contiguous()
 
 
+def upsample_flow_warp(coords1: torch.Tensor, mask: torch.Tensor, frame: torch.Tensor, sign: float = 1.0, want_flow: bool = True):
+    """RAFT.upsample_flow (raft.py:72-83) + the bilinear backward warp of one shared uint8 frame [8h,8w,3] in ONE kernel.
+    coords1 f32 [B,h,w,2], mask f32 [B,h,w,576] -> (flow_up f32 [B,8h,8w,2] or None, warped u8 [B,8h,8w,3])."""
+    c = _chk(coords1, "coords1", torch.float32)
+    m = _chk(mask, "mask", torch.float32)
+    fr = _chk(frame, "frame", torch.uint8)
+    B, h, w, _ = c.shape
+    if tuple(fr.shape) != (8 * h, 8 * w, 3) or tuple(m.shape) != (B, h, w, 576):
+        raise RuntimeError("shapes: coords1 [B,h,w,2], mask [B,h,w,576], frame [8h,8w,3]")
+    flow = torch.empty((B, 8 * h, 8 * w, 2), dtype=torch.float32, device=c.device) if want_flow else None
+    warped = torch.empty((B, 8 * h, 8 * w, 3), dtype=torch.uint8, device=c.device)
+    check(_lib.lib().ofx_upsample_flow_warp(_ptr(c), _ptr(m), _ptr(flow) if want_flow else C.c_void_p(0), _ptr(fr), _ptr(warped), B, h, w,
+                                            float(sign), _stream()), "ofx_upsample_flow_warp")
+    return flow, warped
+
+
 def corr_lookup(pyr: Sequence[torch.Tensor], coords: torch.Tensor, B: int, h: int, w: int, radius: int = 4) -> torch.Tensor:
     """coords f32 [B,h,w,2] (x,y) -> [B,h,w,L*(2r+1)^2] (channels-last version of CorrBlock.__call__)."""
     c = _chk(coords, "coords", torch.float32)

@@ -109,13 +109,19 @@ class RaftEngine:
     @torch.no_grad()
     def forward(self, image1: torch.Tensor, image2: torch.Tensor, iters: int = 20, bgr: bool = False,
                 alternate_corr: bool = False, want_low: bool = False, serial: bool = False, separate_stats: bool = False,
-                fused_lookup: bool = False):
+                fused_lookup: bool = False, warp_frame: Optional[torch.Tensor] = None, warp_sign: float = 1.0,
+                want_flow: bool = True):
         """image1: uint8 [B,H,W,3] or [H,W,3] (shared by the batch); image2 likewise.  Flow is defined
         on image1's grid and points into image2.  Returns flow_up f32[B,H,W,2] (and flow_low).
         serial=True keeps every launch on the current stream (small batches otherwise overlap their
         independent chains on the engine's side streams; results are identical).  separate_stats=True (diagnostic) takes the
         instance-norm statistics with their own f64 pass instead of out of the convolution epilogues.  fused_lookup=True (opt-in) runs
-        the correlation lookup and convc1 as one kernel (the `corr` stage buffer is then not produced)."""
+        the correlation lookup and convc1 as one kernel (the `corr` stage buffer is then not produced).
+        warp_frame: uint8 [H,W,3] (one frame shared by the batch -- the rendered AI key frame): its bilinear backward warp along the
+        final flow is produced INSIDE the convex upsample (`ofx_raft_forward_warp`; warp_sign +1 = pdcnet_of.warp_frame's convention,
+        -1 = ofgen.warp_frame's) and returned after the flow: (flow_up[, flow_low], warped u8 [B,H,W,3]) -- bit-identical to
+        `ops.warp(warp_frame, flow_up, mode="bilinear")`.  want_flow=False skips writing the full-resolution flow (None is returned in
+        its place)."""
         for nm, t in (("image1", image1), ("image2", image2)):
             if not t.is_cuda:
                 raise RuntimeError(f"{nm} must be a CUDA tensor")
@@ -140,27 +146,40 @@ class RaftEngine:
             flags |= FLAG_SHARED_IMG2
         if alternate_corr:
             flags |= FLAG_ALT_CORR
+        if warp_frame is not None:
+            if not warp_frame.is_cuda or warp_frame.dtype != torch.uint8 or tuple(warp_frame.shape) != (H, W, 3):
+                raise RuntimeError(f"warp_frame must be a CUDA uint8 tensor [{H},{W},3] (the padded frame size)")
+            if warp_sign not in (1.0, -1.0):
+                raise ValueError("warp_sign must be +1 or -1")
+            warp_frame = warp_frame.contiguous()
+        elif not want_flow:
+            raise ValueError("want_flow=False only makes sense together with warp_frame")
         max_pairs = self.max_pairs(H, W)
         if B > max_pairs:
-            ups, lows = [], []
+            outs = []
             for b0 in range(0, B, max_pairs):
                 a = image1 if sh1 else image1[b0:b0 + max_pairs]
                 c = image2 if sh2 else image2[b0:b0 + max_pairs]
                 r = self.forward(a, c, iters=iters, bgr=bgr, alternate_corr=alternate_corr, want_low=want_low, serial=serial, separate_stats=separate_stats,
-                                 fused_lookup=fused_lookup)
-                ups.append(r[0] if want_low else r)
-                if want_low:
-                    lows.append(r[1])
-            return (torch.cat(ups), torch.cat(lows)) if want_low else torch.cat(ups)
+                                 fused_lookup=fused_lookup, warp_frame=warp_frame, warp_sign=warp_sign, want_flow=want_flow)
+                outs.append(r if isinstance(r, tuple) else (r,))
+            cat = tuple(None if parts[0] is None else torch.cat(parts) for parts in zip(*outs))
+            return cat if len(cat) > 1 else cat[0]
         ws = self._workspace(B, H, W)
-        flow_up = torch.empty((B, H, W, 2), dtype=torch.float32, device=self.device)
+        flow_up = torch.empty((B, H, W, 2), dtype=torch.float32, device=self.device) if want_flow else None
         flow_low = torch.empty((B, H // 8, W // 8, 2), dtype=torch.float32, device=self.device) if want_low else None
         stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-        check(_lib.lib().ofx_raft_forward(self._h, C.c_void_p(i1.data_ptr()), C.c_void_p(i2.data_ptr()), B, H, W, int(iters),
-                                          flags, C.c_void_p(flow_up.data_ptr()),
-                                          C.c_void_p(flow_low.data_ptr() if want_low else 0),
-                                          C.c_void_p(ws.data_ptr()), ws.numel(), stream), "ofx_raft_forward")
-        return (flow_up, flow_low) if want_low else flow_up
+        fu = C.c_void_p(flow_up.data_ptr() if want_flow else 0)
+        fl = C.c_void_p(flow_low.data_ptr() if want_low else 0)
+        if warp_frame is None:
+            check(_lib.lib().ofx_raft_forward(self._h, C.c_void_p(i1.data_ptr()), C.c_void_p(i2.data_ptr()), B, H, W, int(iters),
+                                              flags, fu, fl, C.c_void_p(ws.data_ptr()), ws.numel(), stream), "ofx_raft_forward")
+            return (flow_up, flow_low) if want_low else flow_up
+        warped = torch.empty((B, H, W, 3), dtype=torch.uint8, device=self.device)
+        check(_lib.lib().ofx_raft_forward_warp(self._h, C.c_void_p(i1.data_ptr()), C.c_void_p(i2.data_ptr()), B, H, W, int(iters), flags,
+                                               fu, fl, C.c_void_p(warp_frame.data_ptr()), float(warp_sign), C.c_void_p(warped.data_ptr()),
+                                               C.c_void_p(ws.data_ptr()), ws.numel(), stream), "ofx_raft_forward_warp")
+        return (flow_up, flow_low, warped) if want_low else (flow_up, warped)
 
     @torch.no_grad()
     def forward_pairs(self, images: torch.Tensor, idx1, idx2, iters: int = 20, bgr: bool = False) -> torch.Tensor:

@@ -391,6 +391,42 @@ def test_corr_volume_pyramid_and_lookup(cuda, shape):
         assert err < 1e-4, (amp, err)
 
 
+@pytest.mark.parametrize("shape", [(4, 16, 24), (5, 12, 9), (4, 17, 10), (6, 96, 64), (2, 17, 10)])
+@pytest.mark.parametrize("sign", [1.0, -1.0])
+def test_upsample_flow_with_the_warp_inside_is_the_two_kernels_bit_for_bit(cuda, shape, sign):
+    """`ofx_upsample_flow_warp` samples the shared key frame while the flow of the four fine pixels of a lane is still in
+    registers.  It must be the composition it replaces, byte for byte: `ofx_upsample_flow` (raft.py:72-83) then the bilinear
+    `ofx_warp_u8` of one shared frame (pdcnet_of.py:34-42 / ofgen_keyframe_inpaint.py:92-98) -- whose own parity against the
+    oracles is pinned elsewhere in this file -- flows that leave the frame included."""
+    ops = _ops()
+    B, h, w = shape
+    g = torch.Generator().manual_seed(41)
+    coords = RO.coords_grid(B, h, w) + (torch.rand((B, 2, h, w), generator=g) - 0.5) * 9.0
+    coords[0, :, 0, 0] += 500.0                                            # far outside: zeros padding
+    mask = torch.randn((B, 576, h, w), generator=g) * 2.0
+    frame = torch.randint(0, 256, (8 * h, 8 * w, 3), generator=g, dtype=torch.uint8).cuda()
+    c, m = nhwc(coords), nhwc(mask)
+    flow_ref = ops.upsample_flow(c, m)
+    warped_ref = ops.warp(frame, flow_ref, mode="bilinear", sign=sign)
+    flow, warped = ops.upsample_flow_warp(c, m, frame, sign=sign)
+    assert torch.equal(flow, flow_ref)
+    if B >= 4:      # `ofx_warp_u8` hands batches of >= 4 frames to the shared-key-frame kernel whose sampling function the fused kernel calls
+        assert torch.equal(warped, warped_ref)
+    else:           # smaller batches take the generic bilinear kernel (weights form, contraction off): 1 LSB apart on rounding ties only
+        d = (warped.int() - warped_ref.int()).abs()
+        assert d.max().item() <= 1 and (d > 0).float().mean().item() < 1e-3
+    none, warped2 = ops.upsample_flow_warp(c, m, frame, sign=sign, want_flow=False)
+    assert none is None and torch.equal(warped2, warped)
+    # against the warp oracle directly (bilinear, zeros outside): u8 rounding of an fp32 blend
+    from oracle import warp_oracle as WO2
+    ref0 = WO2.warp_frame(frame.cpu().numpy(), flow_ref[0].cpu().numpy(), mode="bilinear", convention="pdcnet" if sign > 0 else "raft")
+    d0 = np.abs(warped[0].cpu().numpy().astype(np.int32) - ref0.astype(np.int32))
+    assert d0.max() <= 1 and (d0 > 0).mean() < 2e-3
+    # and the flow against the oracle (the upsample arithmetic moved into a shared inline function this round)
+    ref = RO.upsample_flow(coords - RO.coords_grid(B, h, w), mask)
+    assert (nchw(flow) - ref).abs().max().item() < 2e-3 * max(1.0, ref.abs().max().item())
+
+
 @pytest.mark.parametrize("shape", [(2, 16, 24), (1, 12, 8), (3, 17, 9), (1, 96, 64)])
 def test_corr_lookup_fused_into_convc1(cuda, shape):
     """`ofx_corr_lookup_convc1`: CorrBlock.__call__ (corr.py:29-50) + relu(convc1(.)) (update.py:79-86) in one kernel, against

@@ -414,3 +414,27 @@ def test_epilogue_statistics_on_degenerate_frames(cuda, raft_sd, kind, cnet_norm
         assert _epe(up, up_ref) < 1e-3, (sep, _epe(up, up_ref))
     assert (res[False][1] - res[True][1]).abs().max().item() < 2e-3 * scale
     assert _epe(res[False][0], res[True][0]) < 5e-4
+
+
+def test_forward_with_the_warp_inside_the_upsample(engine, raft_sd):
+    """`RaftEngine.forward(warp_frame=...)` (ofx_raft_forward_warp): the AI key frame is warped inside the convex upsample.  Same flow,
+    and the warped frames are byte for byte `ops.warp(key_ai, flow, 'bilinear')` of the plain forward -- for a frame size that needs
+    InputPadder as well, for both warp conventions, and with the full-resolution flow left unwritten."""
+    from sd_animation_optical_flow_amd import ops
+    for (H, W, B, seed) in ((128, 160, 5, 51), (256, 384, 4, 52)):       # >= 4 frames: ops.warp then takes the same sampling kernel
+        key, frames = _frames(seed, B, H, W)
+        g = torch.Generator().manual_seed(seed)
+        key_ai = torch.randint(0, 256, (H, W, 3), generator=g, dtype=torch.uint8).cuda()
+        flow = engine.forward(frames.cuda(), key.cuda(), iters=8)
+        for sign in (1.0, -1.0):
+            ref = ops.warp(key_ai, flow, mode="bilinear", sign=sign)
+            f2, warped = engine.forward(frames.cuda(), key.cuda(), iters=8, warp_frame=key_ai, warp_sign=sign)
+            assert torch.equal(f2, flow) and torch.equal(warped, ref)
+        none, warped = engine.forward(frames.cuda(), key.cuda(), iters=8, warp_frame=key_ai, want_flow=False)
+        assert none is None and torch.equal(warped, ops.warp(key_ai, flow, mode="bilinear"))
+        f3, lo3, w3 = engine.forward(frames.cuda(), key.cuda(), iters=8, warp_frame=key_ai, want_low=True)
+        assert torch.equal(f3, flow) and tuple(lo3.shape) == (B, H // 8, W // 8, 2) and torch.equal(w3, warped)
+    with pytest.raises(RuntimeError):
+        engine.forward(frames.cuda(), key.cuda(), iters=1, warp_frame=key_ai[:100])          # not the frame size
+    with pytest.raises(ValueError):
+        engine.forward(frames.cuda(), key.cuda(), iters=1, want_flow=False)                  # nothing to return

@@ -22,6 +22,7 @@ FAMILIES = [
     ("corr_volume_gemm", lambda n, gy: "igemm_kernel" in n and gy > 1),
     ("corr_lookup", lambda n, gy: "corr_lookup" in n),
     ("pyramid_pool", lambda n, gy: "pyramid_pool_kernel" in n),
+    ("upsample_warp", lambda n, gy: "upsample_warp_kernel" in n),
     ("upsample", lambda n, gy: "upsample_kernel" in n),
     ("flow_head", lambda n, gy: "flow_head_kernel" in n),
     ("warp", lambda n, gy: "warp_u8c3_x4_kernel" in n or "warp_kernel" in n or "warp_bilinear" in n),
