@@ -24,14 +24,24 @@
 // Bound: the GEMM (2 * 336 * 256 flop per pixel on the fp32 MFMA: >= 430 us per 64-pair launch), not HBM -- fusing can only hide the
 // gather (265 us of HBM time) under it and drop the row's 1.02 GB round trip.
 //
-// MEASURED (tools/lookup_bench.py, B = 64 at 512x768): 906-1085 us against 886 us for the two kernels it replaces (lookup 355 +
-// convc1 530), results identical to 7e-7.  It does NOT win yet, so the RAFT executor keeps the two-kernel schedule by default
-// (OFX_RAFT_FUSED_LOOKUP / OFX_FUSED_LOOKUP=1 select this kernel).  Why, from the probes (each role idled in turn): the consumers alone
-// need 710-735 us = 89-92 TFLOP/s -- two MFMA-issuing waves per SIMD do not hide their own LDS / L2 latencies the way the convolution
-// kernel's four do (123 TFLOP/s on the same GEMM) -- and the producers alone need 620-690 us: the gather is instruction- and
-// LDS-latency-bound at eight producer waves per CU (87 VALU + 42 SALU + 8 LDS instructions per pixel-level), where the stand-alone
-// lookup kernel keeps 32 waves per CU in flight.  A variant without roles (every wave gathers, then multiplies; four workgroups per
-// CU) measured 1300 us.  The 128-register budget the accumulators impose is what caps the waves per CU in every variant.
+// MEASURED (tools/lookup_bench.py, B = 64 at 512x768): 906-1200 us (it varies from box to box) against 886 us for the two kernels it
+// replaces (lookup 355 + convc1 530), results identical to 7e-7.  It does NOT win yet, so the RAFT executor keeps the two-kernel
+// schedule by default (OFX_RAFT_FUSED_LOOKUP / OFX_FUSED_LOOKUP=1 select this kernel).  Why, from probes that idle one side or skip one
+// stream at a time:
+//   consumers alone            710-750 us (89-92 TFLOP/s); without their stores 634, without their weight loads as well 615 --
+//                              i.e. the bare MFMA loop runs at 0.70 of the fp32 peak with 16 MFMAs per k-step and two MFMA-issuing
+//                              waves per SIMD: the same ~400 matrix-pipe cycles lost per (operand fetch -> MFMA block) that the
+//                              convolution kernel shows on its 16-MFMA tiles, which hides them behind four waves
+//                              per SIMD and 32-48 MFMAs per block.  Weight loads from L2 are free (prefetched two steps ahead; the
+//                              scheduler must be stopped from sinking them, see consume_level); dependent vs round-robin accumulator
+//                              order makes no difference; the dword-store epilogue costs 116 us.
+//   producers alone            620-800 us: 72 VALU + 24 SALU + 8 LDS instructions per pixel-level at 8 producer waves per CU, where
+//                              the stand-alone lookup keeps 32 waves per CU in flight and is HBM-bound.  Eight items in flight instead
+//                              of four, two LDS windows per wave (staging never waits for the previous item's reads) and taps read in
+//                              one batch measured no better.
+//   a role-free variant        (every wave gathers, then multiplies; four workgroups per CU) 1300 us.
+// The 64 accumulator registers per lane cap every variant at 128 VGPRs x 16 waves per CU; the next design step is a consumer with 32
+// or more MFMAs per block at four waves per SIMD, which needs the accumulators halved (32 channels per wave) or AGPR-resident.
 #include "ofx_internal.h"
 
 #include <algorithm>
@@ -70,7 +80,7 @@ struct LcArgs {
 // A wave's work on a tile is 64 items: (level 0..3) x (its 16 pixels).  The block loads of an item go out kDepth items ahead of the
 // item being blended -- across level chunks and across tiles, so the gather never restarts cold behind a barrier: HBM latency under
 // this access pattern is ~3 us and only the depth of that queue hides it.
-constexpr int kDepth = 4;            // items in flight per producer wave (2 x 16-byte loads each: 32 VGPRs); divides 64.  8 measured no faster
+constexpr int kDepth = 4;            // items in flight per producer wave (2 x 16-byte loads each: 32 VGPRs); divides 64
 constexpr int kItems = 4 * 16;
 
 struct ProdConst {                   // per-lane constants of the block gather (corr.hip: 12 slots x 8 pieces of 16 B in two rounds) and of the taps
@@ -124,42 +134,49 @@ __device__ __forceinline__ void issue_item(const LcArgs& a, const ProdConst& pc,
     }
 }
 
-// window of the item (in registers) -> this wave's LDS scratch -> 81 bilinear taps -> row p of the A chunk
-__device__ __forceinline__ void blend_item(const ProdConst& pc, int l, float2 c, const v4i (&v)[2], float* __restrict__ win,
-                                           float* __restrict__ arow, int lane) {
+// window of an item (in registers) -> one of this wave's two LDS scratch windows.  LDS instructions of one wavefront execute in issue
+// order, so the tap reads that follow in program order see these writes without waiting for them.
+__device__ __forceinline__ void stage_window(const ProdConst& pc, const v4i (&v)[2], float* __restrict__ win) {
 #pragma unroll
     for (int rr = 0; rr < 2; ++rr)
         if (pc.slot_ok[rr]) *reinterpret_cast<v4i*>(win + pc.lds_off[rr]) = v[rr];
+}
+
+struct Taps { float v[2][4]; };
+
+// the item's 2 x 4 tap values per lane (81 bilinear footprints), read from its staged window
+__device__ __forceinline__ Taps read_taps(const ProdConst& pc, int l, float2 c, const float* __restrict__ win) {
     const float inv = 1.0f / (float)(1 << l);
     const float xs = c.x * inv, ys = c.y * inv;
     const bool sane = fabsf(xs) < 1.0e7f && fabsf(ys) < 1.0e7f;
-    const float xf = floorf(xs), yf = floorf(ys);
-    const float fx = xs - xf, fy = ys - yf;
-    const float w00 = (1.f - fx) * (1.f - fy), w01 = fx * (1.f - fy), w10 = (1.f - fx) * fy, w11 = fx * fy;
-    const int wx = sane ? (int)xf - kR : -100000, wy = sane ? (int)yf - kR : -100000;
-    // each wavefront owns its window: LDS operations of one wave complete in order
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const int wx = sane ? (int)floorf(xs) - kR : -100000, wy = sane ? (int)floorf(ys) - kR : -100000;
     const float* sl = win + (wy & 3) * kWinCols + (wx & 7);
-    float tv[2][4];
+    Taps t;
 #pragma unroll
-    for (int rr = 0; rr < 2; ++rr) {                            // all eight taps in flight together
+    for (int rr = 0; rr < 2; ++rr) {
         const float* b = sl + pc.tap_off[rr];
-        tv[rr][0] = b[0]; tv[rr][1] = b[1]; tv[rr][2] = b[kWinCols]; tv[rr][3] = b[kWinCols + 1];
+        t.v[rr][0] = b[0]; t.v[rr][1] = b[1]; t.v[rr][2] = b[kWinCols]; t.v[rr][3] = b[kWinCols + 1];
     }
+    return t;
+}
+
+// bilinear blend of the taps -> row of the A chunk
+__device__ __forceinline__ void blend_taps(int l, float2 c, const Taps& t, float* __restrict__ arow, int lane) {
+    const float inv = 1.0f / (float)(1 << l);
+    const float xs = c.x * inv, ys = c.y * inv;
+    const float fx = xs - floorf(xs), fy = ys - floorf(ys);
+    const float w00 = (1.f - fx) * (1.f - fy), w01 = fx * (1.f - fy), w10 = (1.f - fx) * fy, w11 = fx * fy;
     float ta[2];
 #pragma unroll
     for (int rr = 0; rr < 2; ++rr) {
-        float acc = tv[rr][0] * w00;
-        acc = acc + tv[rr][1] * w01;
-        acc = acc + tv[rr][2] * w10;
-        acc = acc + tv[rr][3] * w11;
+        float acc = t.v[rr][0] * w00;
+        acc = acc + t.v[rr][1] * w01;
+        acc = acc + t.v[rr][2] * w10;
+        acc = acc + t.v[rr][3] * w11;
         ta[rr] = acc;
     }
     arow[lane] = ta[0];
     if (lane < kTaps - 64) arow[64 + lane] = ta[1];
-    __builtin_amdgcn_wave_barrier();                            // the window is rewritten by the next item
 }
 
 // ---- consumer: one level chunk (84 k) of a 64 x 64 output block per wave -----------------------------------------------
@@ -209,26 +226,30 @@ __device__ __forceinline__ void consume_level(const float* __restrict__ Achunk, 
                 fa[0][i] = make_float4(t.x, t.y, 0.f, 0.f);
             }
         }
+        // the scheduler must not sink the loads just issued down to their uses two / one steps later (left alone it does, to save
+        // registers, and every step then waits out a full L2 round trip)
+        __builtin_amdgcn_sched_barrier(0);
         const float4 (&f)[2] = fa[g & 1];
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(f[i].x, b.j0.x, acc[i][0], 0, 0, 0);
-            acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(f[i].y, b.j0.y, acc[i][0], 0, 0, 0);
-            acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(f[i].x, b.j1.x, acc[i][1], 0, 0, 0);
-            acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(f[i].y, b.j1.y, acc[i][1], 0, 0, 0);
-            if (g < 10) {
-                acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(f[i].z, b.j0.z, acc[i][0], 0, 0, 0);
-                acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(f[i].w, b.j0.w, acc[i][0], 0, 0, 0);
-                acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(f[i].z, b.j1.z, acc[i][1], 0, 0, 0);
-                acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(f[i].w, b.j1.w, acc[i][1], 0, 0, 0);
-            }
+        // round-robin over the four accumulators: consecutive MFMAs never depend on each other
+#define OFX_LC_MFMA(S)                                                                                      \
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(f[0].S, b.j0.S, acc[0][0], 0, 0, 0);               \
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(f[0].S, b.j1.S, acc[0][1], 0, 0, 0);               \
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(f[1].S, b.j0.S, acc[1][0], 0, 0, 0);               \
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(f[1].S, b.j1.S, acc[1][1], 0, 0, 0);
+        OFX_LC_MFMA(x)
+        OFX_LC_MFMA(y)
+        if (g < 10) {
+            OFX_LC_MFMA(z)
+            OFX_LC_MFMA(w)
         }
+#undef OFX_LC_MFMA
+        __builtin_amdgcn_sched_barrier(0);
     }
 }
 
 __global__ __launch_bounds__(512, 4) void lookup_convc1_kernel(const LcArgs a) {
     __shared__ __attribute__((aligned(16))) float As[2][kBM * kLDA];            // 43 008 B
-    __shared__ __attribute__((aligned(16))) float win[4][kWinRows * kWinCols];  //  6 144 B
+    __shared__ __attribute__((aligned(16))) float win[4][2][kWinRows * kWinCols];  // 12 288 B: two windows per producer wave
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // the three padding columns of both chunks: zero once (the producers write taps 0..80 only)
     if (tid < 2 * kBM) {
@@ -240,7 +261,8 @@ __global__ __launch_bounds__(512, 4) void lookup_convc1_kernel(const LcArgs a) {
     if (wave >= 4) {
         // ------------------------------------------------------------------ producers
         const int pw = (wave - 4) * 16;                        // this wave's 16 pixels of the tile
-        float* w = win[wave - 4];
+        float* const w0 = win[wave - 4][0];
+        float* const w1 = win[wave - 4][1];
         const ProdConst pc = prod_const(lane);
         v4i v[kDepth][2];
         int t = blockIdx.x;
@@ -251,16 +273,24 @@ __global__ __launch_bounds__(512, 4) void lookup_convc1_kernel(const LcArgs a) {
         float2 cxy = reinterpret_cast<const float2*>(a.coords)[min(m_w + (lane & 15), a.M - 1)];
 #pragma unroll
         for (int q = 0; q < kDepth; ++q) issue_item(a, pc, q >> 4, q & 15, m_w, cxy, v[q]);
+        // software pipeline over items: [tap reads of item q] [window of item q + 1 staged] [loads of item q + 1 + kDepth issued]
+        // [blend of item q].  Two LDS windows alternate, so staging never waits for the reads of the item before.
+        stage_window(pc, v[0], w0);
+        issue_item(a, pc, kDepth >> 4, kDepth & 15, m_w, cxy, v[0]);
         for (; t < a.ntiles; t += G) {
             const long m_next = (long)min(t + G, a.ntiles - 1) * kBM + pw;      // past the last tile: harmless re-reads of the last one
             const float2 cxy_next = reinterpret_cast<const float2*>(a.coords)[min(m_next + (lane & 15), a.M - 1)];
 #pragma unroll
             for (int q = 0; q < kItems; ++q) {
                 const int l = q >> 4, p = q & 15;
-                blend_item(pc, l, pixel_coords(cxy, p), v[q % kDepth], w, &As[l & 1][(pw + p) * kLDA], lane);
-                const int qn = q + kDepth;                     // the registers are free again: the item kDepth ahead goes out now
-                if (qn < kItems) issue_item(a, pc, qn >> 4, qn & 15, m_w, cxy, v[q % kDepth]);
-                else issue_item(a, pc, (qn - kItems) >> 4, (qn - kItems) & 15, m_next, cxy_next, v[q % kDepth]);
+                const float2 c = pixel_coords(cxy, p);
+                const Taps tp = read_taps(pc, l, c, (q & 1) ? w1 : w0);
+                const int q1 = q + 1;                          // its window is staged now, behind the reads above
+                stage_window(pc, v[q1 % kDepth], (q1 & 1) ? w1 : w0);
+                const int qn = q1 + kDepth;                    // the registers are free again: the item kDepth further goes out
+                if (qn < kItems) issue_item(a, pc, qn >> 4, qn & 15, m_w, cxy, v[q1 % kDepth]);
+                else issue_item(a, pc, (qn - kItems) >> 4, (qn - kItems) & 15, m_next, cxy_next, v[q1 % kDepth]);
+                blend_taps(l, c, tp, &As[l & 1][(pw + p) * kLDA], lane);
                 if (p == 15) __syncthreads();                  // level chunk l is complete
             }
             m_w = m_next;
