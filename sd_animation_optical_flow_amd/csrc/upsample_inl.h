@@ -7,6 +7,14 @@
 #pragma once
 #include "ofx_internal.h"
 
+// the 9 x 64 mask logits of a pixel are read exactly once: non-temporal loads keep them from displacing the key frame and the
+// coordinates in L2 (tools/upsample_warp_bench.py: 263 -> 250 us per 64 frames; non-temporal STORES of the outputs measured slower)
+typedef float ofx_f4v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 ofx_nt_load4(const float4* p) {
+    const ofx_f4v v = __builtin_nontemporal_load(reinterpret_cast<const ofx_f4v*>(p));
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+
 struct OfxUpLane {
     bool valid;
     int x, y, i, j;          // coarse pixel, sub-row, first sub-column
@@ -33,7 +41,7 @@ __device__ __forceinline__ OfxUpLane ofx_upsample_lane(const float* __restrict__
     const float* mk = mask + m * 576 + q * 4;
     float4 lg[9];
 #pragma unroll
-    for (int k = 0; k < 9; ++k) lg[k] = *reinterpret_cast<const float4*>(mk + k * 64);
+    for (int k = 0; k < 9; ++k) lg[k] = ofx_nt_load4(reinterpret_cast<const float4*>(mk + k * 64));
     float4 mx = lg[0];
 #pragma unroll
     for (int k = 1; k < 9; ++k) {
