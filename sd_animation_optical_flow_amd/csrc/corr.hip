@@ -240,6 +240,7 @@ constexpr int kWinRows = 16, kWinCols = 24;   // 4 x 3 block slots per level
 // pyramid level: two rounds of block loads (12 slots x 8 pieces) and two rounds of outputs (81 channels) per level.
 typedef int v4i __attribute__((ext_vector_type(4)));
 
+template <int AUX>
 __global__ __launch_bounds__(256) void corr_lookup_blocked_kernel(const LookupBArgs a) {
     __shared__ __attribute__((aligned(16))) float win[4][2 * kWinRows * kWinCols];
     constexpr int r = 4, rd = 9, kLvl = kWinRows * kWinCols;
@@ -292,7 +293,7 @@ __global__ __launch_bounds__(256) void corr_lookup_blocked_kernel(const LookupBA
                 const int by = (wy[l] >> 2) + bj[rr], bx = (wx[l] >> 3) + bi[rr];
                 const bool ok = slot_ok[rr] && (unsigned)by < (unsigned)a.hb[l] && (unsigned)bx < (unsigned)a.wb[l];
                 const int voff = ((__mul24(by, a.wb[l]) + bx) << 7) + (part << 4);
-                v[l * 2 + rr] = __builtin_amdgcn_raw_buffer_load_b128(rs, ok ? voff : -1, 0, 0);   // out of range -> zeros
+                v[l * 2 + rr] = __builtin_amdgcn_raw_buffer_load_b128(rs, ok ? voff : -1, 0, AUX);   // out of range -> zeros
             }
         }
         float* o = a.out + m * (long)a.ldo;
@@ -629,7 +630,9 @@ int ofx_corr_lookup(const float* const* pyr, const float* coords, float* out, in
             a.slice[l] = (long)a.hb[l] * a.wb[l] * 32;
         }
         a.coords = coords; a.out = out; a.ldo = ldo; a.M = M;
-        hipLaunchKernelGGL(corr_lookup_blocked_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, s, a);
+        // window blocks are read once per iteration out of a 12.8 GB pyramid: non-temporal loads (aux bit 1 on gfx950) keep them from
+        // displacing the row the kernel is writing for convc1 (tools/lookup_bench.py: 363 -> 353 us, lookup + convc1 889 -> 875 us)
+        hipLaunchKernelGGL(corr_lookup_blocked_kernel<2>, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, s, a);
         return ofx_launch_status();
     }
     LookupArgs a{};
