@@ -331,7 +331,11 @@ __global__ __launch_bounds__(NT) void mask_rows_kernel(const BitArgs a, const in
             const int y = y0 - r + row, x = (ch << 8) + (lane << 2);
             ok[u] = it < nitems && (unsigned)y < (unsigned)H && x < W;
             v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (ok[u]) v[u] = *reinterpret_cast<const float4*>(cbase + (long)y * W + x);
+            if (ok[u]) {   // the confidence map is read once: non-temporal
+                typedef float f4v __attribute__((ext_vector_type(4)));
+                const f4v t = __builtin_nontemporal_load(reinterpret_cast<const f4v*>(cbase + (long)y * W + x));
+                v[u] = make_float4(t.x, t.y, t.z, t.w);
+            }
         }
 #pragma unroll
         for (int u = 0; u < kRowBatch; ++u) {
