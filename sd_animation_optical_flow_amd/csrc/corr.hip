@@ -68,7 +68,9 @@ __global__ __launch_bounds__(256) void pyramid_pool_kernel(const PoolArgs a) {
         // level 1 came out of the GEMM (blocked): bring it into the row-major LDS map and go on from there
         const float* l1 = a.lv[1] + p * (long)a.slice[1];
         for (int e = threadIdx.x * 4; e < a.slice[1]; e += 256 * 4) {
-            const float4 v = *reinterpret_cast<const float4*>(l1 + e);
+            typedef float f4v __attribute__((ext_vector_type(4)));
+            const f4v t = __builtin_nontemporal_load(reinterpret_cast<const f4v*>(l1 + e));   // level 1 is read once here
+            const float4 v = make_float4(t.x, t.y, t.z, t.w);
             const int blk = e >> 5, off = e & 31;
             const int by = blk / a.wb[1], bx = blk - by * a.wb[1];
             const int y = (by << 2) + (off >> 3), x = (bx << 3) + (off & 7);

@@ -167,7 +167,9 @@ __global__ __launch_bounds__(256) void inorm_apply_kernel(const float* __restric
     float4* oi = reinterpret_cast<float4*>(out) + (long)b * per;
     const long step = (long)gridDim.x * blockDim.x;             // a multiple of cg: the channel quad stays put
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < per; i += step) {
-        const float4 v = xi[i];
+        typedef float f4v __attribute__((ext_vector_type(4)));
+        const f4v t = __builtin_nontemporal_load(reinterpret_cast<const f4v*>(xi + i));   // the raw convolution output is read once here
+        const float4 v = make_float4(t.x, t.y, t.z, t.w);
         float4 y;
         y.x = (v.x - mu.x) * rs.x; y.y = (v.y - mu.y) * rs.y; y.z = (v.z - mu.z) * rs.z; y.w = (v.w - mu.w) * rs.w;
         if (relu || ri) {
