@@ -265,8 +265,8 @@ __global__ __launch_bounds__(512, 4) void lookup_convc1_kernel(const LcArgs a) {
         float* const w1 = win[wave - 4][1];
         const ProdConst pc = prod_const(lane);
         v4i v[kDepth][2];
-        int t = blockIdx.x;
-        if (t >= a.ntiles) return;                             // (the launcher never starts more workgroups than tiles)
+        int t = blockIdx.x;                                    // (the launcher never starts more workgroups than tiles; a surplus one would
+                                                               // find both roles' tile loops empty and meet no barrier)
         long m_w = (long)t * kBM + pw;
         // lane i holds the coordinates of pixel i % 16 of the wave (one load per tile, a tile ahead: a load per pixel would queue
         // behind the block loads just issued -- vector-memory results return in order -- and serialise the pipeline)
