@@ -18,30 +18,28 @@
 // One s_barrier per level chunk orders the two roles (producers run exactly one chunk ahead).  The weight fragments do
 // not pass through LDS: they are uploaded once in MFMA fragment order (`ofx_lookup_conv_pack`) and every consumer wave
 // streams its own 64 columns from L2 straight into registers, two k-steps ahead of the multiply.  The kernel is
-// persistent (two workgroups per CU walk the tiles), so a producer is already gathering the next tile's level 0 while
+// persistent (one workgroup per CU walks the tiles), so a producer is already gathering the next tile's level 0 while
 // the consumers finish level 3 and store.
 //
 // Bound: the GEMM (2 * 336 * 256 flop per pixel on the fp32 MFMA: >= 430 us per 64-pair launch), not HBM -- fusing can only hide the
 // gather (265 us of HBM time) under it and drop the row's 1.02 GB round trip.
 //
-// MEASURED (tools/lookup_bench.py, B = 64 at 512x768): 906-1200 us (it varies from box to box) against 886 us for the two kernels it
-// replaces (lookup 355 + convc1 530), results identical to 7e-7.  It does NOT win yet, so the RAFT executor keeps the two-kernel
-// schedule by default (OFX_RAFT_FUSED_LOOKUP / OFX_FUSED_LOOKUP=1 select this kernel).  Why, from probes that idle one side or skip one
-// stream at a time:
-//   consumers alone            710-750 us (89-92 TFLOP/s); without their stores 634, without their weight loads as well 615 --
-//                              i.e. the bare MFMA loop runs at 0.70 of the fp32 peak with 16 MFMAs per k-step and two MFMA-issuing
-//                              waves per SIMD: the same ~400 matrix-pipe cycles lost per (operand fetch -> MFMA block) that the
-//                              convolution kernel shows on its 16-MFMA tiles, which hides them behind four waves
-//                              per SIMD and 32-48 MFMAs per block.  Weight loads from L2 are free (prefetched two steps ahead; the
-//                              scheduler must be stopped from sinking them, see consume_level); dependent vs round-robin accumulator
-//                              order makes no difference; the dword-store epilogue costs 116 us.
-//   producers alone            620-800 us: 72 VALU + 24 SALU + 8 LDS instructions per pixel-level at 8 producer waves per CU, where
-//                              the stand-alone lookup keeps 32 waves per CU in flight and is HBM-bound.  Eight items in flight instead
-//                              of four, two LDS windows per wave (staging never waits for the previous item's reads) and taps read in
-//                              one batch measured no better.
-//   a role-free variant        (every wave gathers, then multiplies; four workgroups per CU) 1300 us.
-// The 64 accumulator registers per lane cap every variant at 128 VGPRs x 16 waves per CU; the next design step is a consumer with 32
-// or more MFMAs per block at four waves per SIMD, which needs the accumulators halved (32 channels per wave) or AGPR-resident.
+// MEASURED (tools/lookup_bench.py, B = 64 at 512x768): 950-990 us against 890-935 us on the same boxes for the two kernels it replaces
+// (lookup 335-355 + convc1 530), results identical to 7e-7.  It does NOT win, so the RAFT executor keeps the two-kernel schedule by
+// default (OFX_RAFT_FUSED_LOOKUP / OFX_FUSED_LOOKUP=1 select this kernel).  What the probes say (compile-time switches, OFX_LC_DBG):
+//   * two role-split workgroups per CU (128 VGPRs per wave) cost the consumers dearly: alone they needed 710-750 us -- two MFMA waves of
+//     DIFFERENT workgroups share a SIMD, progress unevenly and wait for each other at every chunk barrier.  ONE workgroup per CU (256
+//     VGPRs per wave, this version): consumers alone 551 us = 118 TFLOP/s, on a par with the convolution kernel on this GEMM (123);
+//   * with 256 VGPRs the producers can keep 16 items (32 block loads) per wave in flight: producers alone 362 us = the stand-alone
+//     lookup's rate.  Shallower queues (4 items at 128 VGPRs) left them latency-bound at 620-800 us;
+//   * together: ~950 us = the SUM of the two, not the maximum.  Producers that only gather and stage (no tap reads, no blend) are free
+//     (549 us with the consumers running); the tap reads + blend + row writes alone, without any global load, cost +190 us; both
+//     together +400 us.  Halving the producers' vector instructions (72 -> 32 per item: the per-tile item table below) changed nothing,
+//     nor did wave priorities, accumulator order, or 16-byte stores through swapped MFMA operands (slower: scattered 16-byte pieces);
+//   * i.e. on one SIMD the blend's LDS-read -> FMA -> LDS-write chains and the MFMA stream do not overlap the way two workgroups of the
+//     convolution kernel overlap each other; what exactly they contend for (LDS return path, issue arbitration) the counters we can
+//     reach do not separate.  A role-free variant (every wave gathers, then multiplies; four workgroups per CU) measured 1300 us, and
+//     the un-fused overlap (lookup of chunk c + 1 on one stream beside convc1 of chunk c on another) nothing at all.
 #include "ofx_internal.h"
 
 #include <algorithm>
@@ -80,7 +78,10 @@ struct LcArgs {
 // A wave's work on a tile is 64 items: (level 0..3) x (its 16 pixels).  The block loads of an item go out kDepth items ahead of the
 // item being blended -- across level chunks and across tiles, so the gather never restarts cold behind a barrier: HBM latency under
 // this access pattern is ~3 us and only the depth of that queue hides it.
-constexpr int kDepth = 4;            // items in flight per producer wave (2 x 16-byte loads each: 32 VGPRs); divides 64
+#ifndef OFX_LC_DBG
+#define OFX_LC_DBG 0   // compile-time probes: 4 = producers skip taps + blend, 8 = skip staging too, 16 = skip the global loads
+#endif
+constexpr int kDepth = 16;           // items in flight per producer wave (2 x 16-byte loads each: 128 VGPRs); divides 64
 constexpr int kItems = 4 * 16;
 
 struct ProdConst {                   // per-lane constants of the block gather (corr.hip: 12 slots x 8 pieces of 16 B in two rounds) and of the taps
@@ -105,32 +106,67 @@ __device__ __forceinline__ ProdConst prod_const(int lane) {
     return c;
 }
 
-// coordinates of pixel p of the wave, from the lane-distributed copy (lane i holds pixel i % 16): scalar after the readlane
-__device__ __forceinline__ float2 pixel_coords(float2 cxy, int p) {
-    return make_float2(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(cxy.x), p)),
-                       __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cxy.y), p)));
+// Vector work on a producer wave is paid in matrix-pipe time of the consumer wave that shares its SIMD (probes in the header), so the
+// per-item arithmetic is kept to what genuinely differs per lane.  Everything that depends only on (pixel, level) -- window origin,
+// block base offset, fractional weights -- is computed ONCE PER TILE, vectorised: lane L of a producer wave = item L of the tile
+// (level L / 16, pixel L % 16: exactly 64 items), and an item's values are broadcast with v_readlane when its turn comes.
+struct ItemTab {
+    int sbase;     // byte offset of block (wy >> 2, wx >> 3) of the window in the pixel's slice of its level (may be negative / past the end)
+    int wxb;       // wx >> 3: block column of the window origin (the column range is the one check the descriptor cannot do)
+    int winoff;    // (wy & 3) * kWinCols + (wx & 7): where the window starts inside the staged 16 x 24 region, in floats
+    float w00, w01, w10, w11;
+};
+
+__device__ __forceinline__ ItemTab item_table(const LcArgs& a, float2 cxy, int lane) {
+    const int l = lane >> 4;
+    const float inv = l == 0 ? 1.0f : l == 1 ? 0.5f : l == 2 ? 0.25f : 0.125f;     // exact: coords / 2**l
+    const int wb = l == 0 ? a.wb[0] : l == 1 ? a.wb[1] : l == 2 ? a.wb[2] : a.wb[3];
+    const float xs = cxy.x * inv, ys = cxy.y * inv;
+    const bool sane = fabsf(xs) < 1.0e7f && fabsf(ys) < 1.0e7f;
+    const float xf = floorf(xs), yf = floorf(ys);
+    const float fx = xs - xf, fy = ys - yf;
+    const int wx = sane ? (int)xf - kR : -100000, wy = sane ? (int)yf - kR : -100000;
+    ItemTab t;
+    t.wxb = wx >> 3;
+    t.sbase = (__mul24(wy >> 2, wb) + t.wxb) << 7;
+    t.winoff = (wy & 3) * kWinCols + (wx & 7);
+    t.w00 = (1.f - fx) * (1.f - fy); t.w01 = fx * (1.f - fy); t.w10 = (1.f - fx) * fy; t.w11 = fx * fy;
+    return t;
 }
 
-// block loads of item (level l, pixel p) of the tile whose first pixel of this wave is m_w
-__device__ __forceinline__ void issue_item(const LcArgs& a, const ProdConst& pc, int l, int p, long m_w, float2 cxy, v4i (&v)[2]) {
+// per-lane, per-level constant of the block gather: byte offset of this lane's 16-byte piece relative to the window's first block, or
+// far out of range for the lanes of round 1 that have no slot (the descriptor then returns zeros)
+struct LaneConst { int off[kLevels][2]; };
+
+__device__ __forceinline__ LaneConst lane_const(const LcArgs& a, const ProdConst& pc) {
+    LaneConst c;
+#pragma unroll
+    for (int l = 0; l < kLevels; ++l)
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr)
+            c.off[l][rr] = pc.slot_ok[rr] ? ((__mul24(pc.bj[rr], a.wb[l]) + pc.bi[rr]) << 7) + (pc.part << 4) : 0x40000000;
+    return c;
+}
+
+__device__ __forceinline__ int bcast_i(int v, int q) { return __builtin_amdgcn_readlane(v, q); }
+__device__ __forceinline__ float bcast_f(float v, int q) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), q)); }
+
+// block loads of item q = (level l, pixel p) of the tile whose first pixel of this wave is m_w.  A block row outside the slice lands
+// outside the descriptor's extent by itself (negative -> huge unsigned, too large -> past the end); only the block COLUMN needs a test.
+__device__ __forceinline__ void issue_item(const LcArgs& a, const ProdConst& pc, const LaneConst& lc, const ItemTab& tab, int q, long m_w,
+                                           v4i (&v)[2]) {
+    const int l = q >> 4, p = q & 15;
     const long m = min(m_w + p, a.M - 1);
     const unsigned m_lo = __builtin_amdgcn_readfirstlane((unsigned)m), m_hi = __builtin_amdgcn_readfirstlane((unsigned)(m >> 32));
     const long mu = (long)(((unsigned long long)m_hi << 32) | m_lo);
-    const float2 c = pixel_coords(cxy, p);
-    const float inv = 1.0f / (float)(1 << l);                   // exact: coords / 2**l
-    const float xs = c.x * inv, ys = c.y * inv;
-    const bool sane = fabsf(xs) < 1.0e7f && fabsf(ys) < 1.0e7f;
-    const int wx = sane ? (int)floorf(xs) - kR : -100000;
-    const int wy = sane ? (int)floorf(ys) - kR : -100000;
-    const int hb = a.hb[l], wb = a.wb[l];
+    const int sbase = bcast_i(tab.sbase, q), wxb = bcast_i(tab.wxb, q);
+    const int wb = a.wb[l];
     const long slice = a.slice[l];
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(a.pyr[l] + mu * slice), (short)0, (int)(slice * 4), 0x00020000);
 #pragma unroll
     for (int rr = 0; rr < 2; ++rr) {
-        const int by = (wy >> 2) + pc.bj[rr], bx = (wx >> 3) + pc.bi[rr];
-        const bool ok = pc.slot_ok[rr] && (unsigned)by < (unsigned)hb && (unsigned)bx < (unsigned)wb;
-        const int voff = ((__mul24(by, wb) + bx) << 7) + (pc.part << 4);
-        v[rr] = __builtin_amdgcn_raw_buffer_load_b128(rs, ok ? voff : -1, 0, 0);   // out of range -> zeros
+        const bool ok = (unsigned)(wxb + pc.bi[rr]) < (unsigned)wb;
+        v[rr] = __builtin_amdgcn_raw_buffer_load_b128(rs, ok ? sbase + lc.off[l][rr] : -1, 0, 0);   // out of range -> zeros
     }
 }
 
@@ -145,12 +181,8 @@ __device__ __forceinline__ void stage_window(const ProdConst& pc, const v4i (&v)
 struct Taps { float v[2][4]; };
 
 // the item's 2 x 4 tap values per lane (81 bilinear footprints), read from its staged window
-__device__ __forceinline__ Taps read_taps(const ProdConst& pc, int l, float2 c, const float* __restrict__ win) {
-    const float inv = 1.0f / (float)(1 << l);
-    const float xs = c.x * inv, ys = c.y * inv;
-    const bool sane = fabsf(xs) < 1.0e7f && fabsf(ys) < 1.0e7f;
-    const int wx = sane ? (int)floorf(xs) - kR : -100000, wy = sane ? (int)floorf(ys) - kR : -100000;
-    const float* sl = win + (wy & 3) * kWinCols + (wx & 7);
+__device__ __forceinline__ Taps read_taps(const ProdConst& pc, const ItemTab& tab, int q, const float* __restrict__ win) {
+    const float* sl = win + bcast_i(tab.winoff, q);
     Taps t;
 #pragma unroll
     for (int rr = 0; rr < 2; ++rr) {
@@ -161,11 +193,8 @@ __device__ __forceinline__ Taps read_taps(const ProdConst& pc, int l, float2 c, 
 }
 
 // bilinear blend of the taps -> row of the A chunk
-__device__ __forceinline__ void blend_taps(int l, float2 c, const Taps& t, float* __restrict__ arow, int lane) {
-    const float inv = 1.0f / (float)(1 << l);
-    const float xs = c.x * inv, ys = c.y * inv;
-    const float fx = xs - floorf(xs), fy = ys - floorf(ys);
-    const float w00 = (1.f - fx) * (1.f - fy), w01 = fx * (1.f - fy), w10 = (1.f - fx) * fy, w11 = fx * fy;
+__device__ __forceinline__ void blend_taps(const ItemTab& tab, int q, const Taps& t, float* __restrict__ arow, int lane) {
+    const float w00 = bcast_f(tab.w00, q), w01 = bcast_f(tab.w01, q), w10 = bcast_f(tab.w10, q), w11 = bcast_f(tab.w11, q);
     float ta[2];
 #pragma unroll
     for (int rr = 0; rr < 2; ++rr) {
@@ -247,7 +276,7 @@ __device__ __forceinline__ void consume_level(const float* __restrict__ Achunk, 
     }
 }
 
-__global__ __launch_bounds__(512, 4) void lookup_convc1_kernel(const LcArgs a) {
+__global__ __launch_bounds__(512, 2) void lookup_convc1_kernel(const LcArgs a) {
     __shared__ __attribute__((aligned(16))) float As[2][kBM * kLDA];            // 43 008 B
     __shared__ __attribute__((aligned(16))) float win[4][2][kWinRows * kWinCols];  // 12 288 B: two windows per producer wave
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -264,37 +293,41 @@ __global__ __launch_bounds__(512, 4) void lookup_convc1_kernel(const LcArgs a) {
         float* const w0 = win[wave - 4][0];
         float* const w1 = win[wave - 4][1];
         const ProdConst pc = prod_const(lane);
+        const LaneConst lc = lane_const(a, pc);
         v4i v[kDepth][2];
         int t = blockIdx.x;                                    // (the launcher never starts more workgroups than tiles; a surplus one would
                                                                // find both roles' tile loops empty and meet no barrier)
         long m_w = (long)t * kBM + pw;
         // lane i holds the coordinates of pixel i % 16 of the wave (one load per tile, a tile ahead: a load per pixel would queue
         // behind the block loads just issued -- vector-memory results return in order -- and serialise the pipeline)
-        float2 cxy = reinterpret_cast<const float2*>(a.coords)[min(m_w + (lane & 15), a.M - 1)];
+        ItemTab tab = item_table(a, reinterpret_cast<const float2*>(a.coords)[min(m_w + (lane & 15), a.M - 1)], lane);
 #pragma unroll
-        for (int q = 0; q < kDepth; ++q) issue_item(a, pc, q >> 4, q & 15, m_w, cxy, v[q]);
+        for (int q = 0; q < kDepth; ++q) issue_item(a, pc, lc, tab, q, m_w, v[q]);
         // software pipeline over items: [tap reads of item q] [window of item q + 1 staged] [loads of item q + 1 + kDepth issued]
         // [blend of item q].  Two LDS windows alternate, so staging never waits for the reads of the item before.
         stage_window(pc, v[0], w0);
-        issue_item(a, pc, kDepth >> 4, kDepth & 15, m_w, cxy, v[0]);
+        issue_item(a, pc, lc, tab, kDepth, m_w, v[0]);
         for (; t < a.ntiles; t += G) {
             const long m_next = (long)min(t + G, a.ntiles - 1) * kBM + pw;      // past the last tile: harmless re-reads of the last one
-            const float2 cxy_next = reinterpret_cast<const float2*>(a.coords)[min(m_next + (lane & 15), a.M - 1)];
+            const ItemTab tab_next = item_table(a, reinterpret_cast<const float2*>(a.coords)[min(m_next + (lane & 15), a.M - 1)], lane);
 #pragma unroll
             for (int q = 0; q < kItems; ++q) {
                 const int l = q >> 4, p = q & 15;
-                const float2 c = pixel_coords(cxy, p);
-                const Taps tp = read_taps(pc, l, c, (q & 1) ? w1 : w0);
+                Taps tp{};
+                if (!(OFX_LC_DBG & 4)) tp = read_taps(pc, tab, q, (q & 1) ? w1 : w0);
                 const int q1 = q + 1;                          // its window is staged now, behind the reads above
-                stage_window(pc, v[q1 % kDepth], (q1 & 1) ? w1 : w0);
+                if (!(OFX_LC_DBG & 8)) stage_window(pc, v[q1 % kDepth], (q1 & 1) ? w1 : w0);
+                else asm volatile("" :: "v"(v[q1 % kDepth][0]), "v"(v[q1 % kDepth][1]));
                 const int qn = q1 + kDepth;                    // the registers are free again: the item kDepth further goes out
-                if (qn < kItems) issue_item(a, pc, qn >> 4, qn & 15, m_w, cxy, v[q1 % kDepth]);
-                else issue_item(a, pc, (qn - kItems) >> 4, (qn - kItems) & 15, m_next, cxy_next, v[q1 % kDepth]);
-                blend_taps(l, c, tp, &As[l & 1][(pw + p) * kLDA], lane);
+                if (!(OFX_LC_DBG & 16)) {
+                if (qn < kItems) issue_item(a, pc, lc, tab, qn, m_w, v[q1 % kDepth]);
+                else issue_item(a, pc, lc, tab_next, qn - kItems, m_next, v[q1 % kDepth]);
+                }
+                if (!(OFX_LC_DBG & 4)) blend_taps(tab, q, tp, &As[l & 1][(pw + p) * kLDA], lane);
                 if (p == 15) __syncthreads();                  // level chunk l is complete
             }
             m_w = m_next;
-            cxy = cxy_next;
+            tab = tab_next;
         }
     } else {
         // ------------------------------------------------------------------ consumers
@@ -411,7 +444,7 @@ int ofx_lookup_conv_launch(const float* const* pyr, const float* coords, const f
     }
     OfxProfScope prof("lookup_convc1", s);
     prof.flops(2.0 * (double)a.M * 336.0 * 256.0);
-    const unsigned grid = (unsigned)std::min<long>(nt, 2L * cus);       // persistent: two workgroups per CU
+    const unsigned grid = (unsigned)std::min<long>(nt, (long)cus);      // persistent: ONE workgroup per CU (256 VGPRs per wave)
     hipLaunchKernelGGL(lookup_convc1_kernel, dim3(grid), dim3(512), 0, s, a);
     return ofx_launch_status();
 }
