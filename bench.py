@@ -205,8 +205,16 @@ def verify_against_oracle(path):
             rec["gpu_epe_vs_f64_px"] = epe(z["flow"][i].astype(np.float64) - r64)
             rec["cpu_fp32_oracle_epe_vs_f64_px"] = epe(ref.astype(np.float64) - r64)
         pairs.append(rec)
+    bn_batch = None
+    if "flow_bn_batch" in z.files:          # the RAFT_2-as-written network (cnet_norm='batch') on pair 0 of the batch
+        a = torch.from_numpy(z["frame"][0]).permute(2, 0, 1)[None].float()
+        _, upb = raft_oracle.raft_forward(sd, a, b, iters=ITERS, cnet_norm="batch")
+        d = z["flow_bn_batch"][0] - upb[0].permute(1, 2, 0).contiguous().numpy()
+        bn_batch = {"pair": int(z["index"][0]), "flow_epe_px": epe(d), "flow_max_err_px": float(np.sqrt((d * d).sum(-1)).max())}
     worst = max(pairs, key=lambda r: r["flow_epe_px"])
     out = dict(worst)
+    if bn_batch:
+        out["raft2_as_written"] = bn_batch
     out.update({"pairs": pairs, "mask_bit_exact": all(r["mask_bit_exact"] for r in pairs),
                 "warp_max_abs_diff_u8": max(r["warp_max_abs_diff_u8"] for r in pairs), "oracle_s": round(time.time() - t0, 2)})
     return out
@@ -265,6 +273,21 @@ def self_launch(args):
     os.execv(sys.executable, cmd)
 
 
+def make_step(eng, frames, key, key_ai, conf, warp_mode="bilinear", separate_warp=False):
+    """The timed step, importable (tests/test_gpu_raft.py runs exactly this on the headline batch): the product's own
+    `clip.FrameSynthesizer` -- what `pipeline.ClipPipeline` and `clip.process_clip` run -- fed by the flow network alone with the clip's
+    synthetic confidence: frame -> key frame flow (shared image2), the AI key frame warped inside the convex upsample when the warp is
+    bilinear, the confidence-threshold mask; plus the path's only exchange, the key-frame broadcast (a no-op on one rank).
+    Returns step() -> (flow f32[B,H,W,2], warped u8 [B,H,W,3], mask u8 [B,H,W])."""
+    from sd_animation_optical_flow_amd import clip
+    synth = clip.FrameSynthesizer(engine=eng, warp_mode=warp_mode, thres=0.95, ksize=7, iters=ITERS, fuse_warp=not separate_warp)
+
+    def step():
+        clip.broadcast_keyframe([key, key_ai], src=0)
+        return synth(frames, key, key_ai, confidence=conf)
+    return step
+
+
 def stub_step_factory(dev):
     """CPU stand-in for the hot path (hidden --stub-step): lets the world_size-2 gloo test drive every line of the
     rank plumbing (init, key-frame broadcast, barrier, timed loop, MAX all-reduce, one JSON line) without a GPU."""
@@ -288,6 +311,7 @@ def main():
     ap.add_argument("--warp-mode", default="bilinear", choices=["bilinear", "bicubic", "cv2_cubic"])
     ap.add_argument("--separate-warp", action="store_true", help="upsample and warp as two kernels (default: the warp runs inside the convex upsample)")
     ap.add_argument("--no-prof", action="store_true", help="do not bracket launches with HIP events")
+    ap.add_argument("--prof-all-steps", action="store_true", help="bracket the launches of every timed step with HIP events (default: the last step only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true", help="skip the oracle check of one sampled pair")
     ap.add_argument("--no-single", action="store_true")
@@ -351,17 +375,7 @@ def main():
         eng = RaftEngine(random_state_dict(0), dev, precision=args.precision)
         frames, key, key_ai, conf = make_clip(B, H, W, dev, rank)
 
-        def step():
-            clip.broadcast_keyframe([key, key_ai], src=0)                 # the path's only exchange
-            if args.warp_mode == "bilinear" and not args.separate_warp:
-                # frame -> key frame, shared image2; the AI key frame is warped inside the convex upsample (one kernel instead of
-                # upsample + warp, same bytes out: flow, warped); then the confidence-threshold mask
-                flow, warped = eng.forward(frames, key, iters=ITERS, warp_frame=key_ai)
-                mask = ops.generate_mask(conf, None, 0.95, 7)
-            else:
-                flow = eng.forward(frames, key, iters=ITERS)
-                warped, mask = ops.warp_and_mask(key_ai, flow, conf, warp_mode=args.warp_mode, thres=0.95, ksize=7)
-            return flow, warped, mask
+        step = make_step(eng, frames, key, key_ai, conf, args.warp_mode, args.separate_warp)
 
     def barrier():
         if dist is not None:
@@ -380,11 +394,18 @@ def main():
     prof = not args.no_prof and ops is not None
     barrier()
     flush_c_stdio()                          # every rank: library banners out before anybody prints a result
-    if prof:
-        ops.prof_enable(2)                   # per layer ("family:layer"); families are re-aggregated below
+    # HIP events bracket every launch of the LAST timed step only (per layer: "family:layer"; families are re-aggregated below).
+    # Two events per launch cost ~1 % of the step (measured round 4: 327.98 ms/step without, 331.31 with, 5 steps each) -- a
+    # command-processor barrier before and after each of ~450 kernels -- so the K - 1 steps before it run as the product runs them;
+    # the roofline's per-kernel durations are the averages over that step's launches (255 convolutions).  --prof-all-steps brackets
+    # every step (what rounds 1-3 did).
+    prof_steps = 0
     last = None
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for i in range(args.steps):
+        if prof and (args.prof_all_steps or i == args.steps - 1):
+            ops.prof_enable(2)               # a host-side flag: nothing is synchronised between the steps
+            prof_steps += 1
         last = step()
     barrier()
     elapsed = time.perf_counter() - t0
@@ -439,7 +460,7 @@ def main():
     if kern:
         conv_names = ["igemm_conv", "igemm_conv_gru_zr", "igemm_conv_gru_q", "igemm_conv_flow"]
         ms, calls = per_launch(conv_names)
-        steps = args.steps
+        steps = max(1, prof_steps)           # the steps whose launches carried events
         if ms > 0:
             executed = sum(kern[n]["flops"] for n in conv_names if n in kern)       # what the launches really multiplied
             if executed <= 0:
@@ -449,7 +470,7 @@ def main():
             out["roofline"] = {"bound": "mfma", "kernel": "igemm_kernel (fp32 MFMA implicit-GEMM conv, all epilogues)",
                                "achieved": round(tf_exec, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                                "frac": round(tf_exec / MFMA_F32_PEAK_TFLOPS, 4), "traffic": None,
-                               "launches_per_step": calls // steps, "avg_launch_ms": round(ms / calls, 4),
+                               "launches_per_step": calls // steps, "avg_launch_ms": round(ms / calls, 4), "profiled_steps": steps,
                                "flops_per_step_executed": executed / steps, "share_of_step": round(ms / steps / ms_per_step, 4),
                                "algorithmic_tflops": round(tf_alg, 2), "algorithmic_flops_per_step": work["conv_flops"],
                                "note": "achieved/frac = FLOPs the launches executed / HIP-event kernel time / fp32-MFMA peak; "
@@ -543,23 +564,52 @@ def main():
         f1 = frames[:1].contiguous()
         c1 = conf[:1].contiguous()
 
-        def one_pair():
-            if args.warp_mode == "bilinear" and not args.separate_warp:
-                eng.forward(f1, key, iters=ITERS, warp_frame=key_ai)
-                ops.generate_mask(c1, None, 0.95, 7)
-            else:
-                fl = eng.forward(f1, key, iters=ITERS)
-                ops.warp_and_mask(key_ai, fl, c1, warp_mode=args.warp_mode, thres=0.95, ksize=7)
+        one_pair = make_step(eng, f1, key, key_ai, c1, args.warp_mode, args.separate_warp)
         for _ in range(2):
             one_pair()
         torch.cuda.synchronize()
-        t1 = time.perf_counter()
         reps = 5
+        t1 = time.perf_counter()
         for _ in range(reps):
             one_pair()
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t1) / reps
+        ops.prof_enable(1)                       # one more call, outside the timing, to count the FLOPs its launches execute
+        one_pair()
+        fam = ops.prof_collect()
+        ops.prof_enable(False)
         out["single_pair"] = {"workload": "BASELINE configs[1]: one 512x768 pair", "ms": round(dt * 1e3, 3), "pairs_per_s": round(1 / dt, 2)}
+        # roofline of the single pair: every launch here is a grid of 100-400 workgroups on 256 CUs, so this is a latency / fill
+        # figure -- executed convolution FLOPs of the whole call over its WALL time against the fp32 MFMA peak (the convolutions are
+        # spread over three streams: summing their event times would count overlapped work twice)
+        cf = sum(v.get("flops", 0.0) for k, v in fam.items() if k.startswith("igemm_conv"))
+        if cf > 0:
+            tf1 = cf / dt / 1e12
+            out["single_pair"]["roofline"] = {"bound": "mfma", "achieved": round(tf1, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                              "frac": round(tf1 / MFMA_F32_PEAK_TFLOPS, 4), "flops_executed": cf,
+                                              "note": "executed convolution FLOPs / wall time of the whole call (flow + warp + mask)"}
+
+    if not args.no_fast and world == 1 and args.precision == "fp32":
+        # `ofgen.RAFT_2` AS WRITTEN (the reference never calls .eval(): context-encoder BatchNorm on each image's own statistics,
+        # ofgen_keyframe_inpaint.py:47-60) on the same clip and the same step: a second copy of the context encoder without folded
+        # statistics + per-image statistics and their apply passes.  Secondary line; `value` stays on the eval-mode network.
+        engb = RaftEngine(random_state_dict(0), dev, precision="fp32", cnet_norm="batch")
+        bstep = make_step(engb, frames, key, key_ai, conf, args.warp_mode, args.separate_warp)
+        fb = bstep()[0]
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            bstep()
+        torch.cuda.synchronize()
+        dtb = (time.perf_counter() - t1) / args.steps
+        out["raft2_as_written"] = {"cnet_norm": "batch", "value": round(B / dtb, 3), "unit": "pairs/s", "ms_per_step": round(dtb * 1e3, 3),
+                                   "note": "the reference's RAFT_2 as written (BatchNorm on per-image statistics); same step, same clip"}
+        if verify_path:
+            import numpy as np
+            z = dict(np.load(verify_path))
+            z["flow_bn_batch"] = fb[:1].cpu().numpy()
+            np.savez(verify_path, **z)
+        del engb, bstep, fb
 
     if not args.no_handoff and world == 1:
         # BASELINE configs[4]'s frame size, the half of it that is on the path: warp/mask outputs -> Pillow-exact inpaint inputs ->

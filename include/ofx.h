@@ -238,7 +238,8 @@ int ofx_split_conv_weight(const float* packed, long n_floats, float* out);
 int ofx_inorm_stats(const float* x, int ld, float* mean, float* rstd, float* scratch,
                     int B, long HW, int C, float eps, void* stream);
 /* out = relu?( (x-mean)*rstd ) ; with res: out = relu( r + relu((x-mean)*rstd) ) where
- * r = res (res_mean==NULL) or (res-res_mean)*res_rstd.  C % 4 == 0 and C <= 1024 (a thread keeps one channel quad:
+ * r = res (res_mean==NULL) or (res-res_mean)*res_rstd -- or relu of that when bit 1 of `relu` is set (relu = 3: the residual is
+ * itself the raw output of a normalised + ReLU layer, RAFT/core/extractor.py:160-165 feeding :44-56).  C % 4 == 0 and C <= 1024 (a thread keeps one channel quad:
  * OFX_EINVAL beyond); any B (batches over 65535 images are split into several launches). */
 int ofx_inorm_apply(const float* x, const float* mean, const float* rstd, const float* res,
                     const float* res_mean, const float* res_rstd, float* out, int B, long HW, int C,
@@ -349,6 +350,14 @@ size_t ofx_raft_workspace_bytes_pairs(const ofx_raft* r, int n_images, int B, in
 int ofx_raft_forward_pairs(ofx_raft* r, const uint8_t* images, int n_images, const int* idx1,
                            const int* idx2, int B, int H, int W, int iters, int flags, float* flow_up,
                            float* flow_low, void* workspace, size_t workspace_bytes, void* stream);
+/* ofx_raft_forward_pairs with the tail of ofx_raft_forward_warp for its FIRST n_warp pairs: warped u8 [n_warp,H,W,3] = the bilinear
+ * backward warp of the shared frame warp_frame u8 [H,W,3] along the final flow of pair b < n_warp, produced inside the convex upsample.
+ * This is the call behind pdcnet_of's `calc_batch_device(..., warp_frame=)`: pairs [0, n) = frame -> key frame (warped: pdcnet_of.py:34-42
+ * in its bilinear mode), pairs [n, 2n) = key frame -> frame (only feed the forward-backward confidence, no warp). */
+int ofx_raft_forward_pairs_warp(ofx_raft* r, const uint8_t* images, int n_images, const int* idx1,
+                                const int* idx2, int B, int H, int W, int iters, int flags, float* flow_up,
+                                float* flow_low, const uint8_t* warp_frame, float warp_sign, int n_warp,
+                                uint8_t* warped, void* workspace, size_t workspace_bytes, void* stream);
 /* debug / stage-parity access to the buffers of the last forward: returns a device pointer and
  * element count for a named intermediate ("fmap1","fmap2","hx","corr","pyr0".."pyr3","mask",...) */
 int ofx_raft_buffer(const ofx_raft* r, const char* name, void** ptr, size_t* nfloats);

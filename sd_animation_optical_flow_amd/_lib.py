@@ -106,6 +106,7 @@ SIGNATURES = {
     "ofx_raft_forward_warp": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p, _p, _p, _f, _p, _p, _z, _p]),
     "ofx_raft_workspace_bytes_pairs": (_z, [_p, _i, _i, _i, _i]),
     "ofx_raft_forward_pairs": (_i, [_p, _p, _i, C.POINTER(_i), C.POINTER(_i), _i, _i, _i, _i, _i, _p, _p, _p, _z, _p]),
+    "ofx_raft_forward_pairs_warp": (_i, [_p, _p, _i, C.POINTER(_i), C.POINTER(_i), _i, _i, _i, _i, _i, _p, _p, _p, _f, _i, _p, _p, _z, _p]),
     "ofx_raft_buffer": (_i, [_p, C.c_char_p, C.POINTER(_p), C.POINTER(_z)]),
 }
 

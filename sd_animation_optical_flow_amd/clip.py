@@ -114,29 +114,62 @@ class SynthesisResult:
 
 
 class FrameSynthesizer:
-    """flow -> warp -> mask for a batch of frames against one key frame, device-resident.
+    """flow -> warp -> mask for a batch of frames against one key frame, device-resident: THE step of the hot path
+    (`bench.py` times exactly this object, `pipeline.ClipPipeline` and `process_clip` run it).
 
-    `flow_fn(frames_u8[B,H,W,3], keyframe_u8[H,W,3]) -> (flow f32[B,H,W,2], confidence f32[B,H,W])`;
-    the default wraps a `pdcnet_of.PDCNetPlus` (`calc_batch_device`)."""
+    Three ways to get flow + confidence, in this order:
+      * `engine` (a `raft.RaftEngine`) with a `confidence` passed to the call -- the flow network alone, one flow per pair;
+        the confidence comes from the caller (a PDCNet-style confidence head, or `bench.py`'s synthetic one);
+      * `algo` (a `pdcnet_of.PDCNetPlus`): `calc_batch_device` -- flow in both directions + forward-backward confidence;
+      * `flow_fn(frames_u8[B,H,W,3], keyframe_u8[H,W,3]) -> (flow f32[B,H,W,2], confidence f32[B,H,W])`: anything else
+        (the CPU tests of the rank logic).
+    With `warp_mode='bilinear'` (the north star's warp) and one shared AI key frame the warp happens INSIDE the convex upsample of
+    the flow network (`ofx_raft_forward_warp` / `ofx_raft_forward_pairs_warp`): the full-resolution flow is never re-read.  The
+    cubic modes and `flow_fn` run upsample, then `ops.warp_and_mask`."""
 
     def __init__(self, algo=None, flow_fn: Optional[Callable] = None, warp_mode: str = "bilinear", thres: float = 0.95,
-                 ksize: int = 7, cmp_gt: bool = False):
-        if flow_fn is None:
-            if algo is None:
-                raise ValueError("need an algo or a flow_fn")
-
-            def flow_fn(frames, key):
-                flow, conf, _ = algo.calc_batch_device(key, frames)
-                return flow, conf
-        self.flow_fn = flow_fn
+                 ksize: int = 7, cmp_gt: bool = False, engine=None, iters: int = 20, bgr: bool = False, fuse_warp: bool = True):
+        if flow_fn is None and algo is None and engine is None:
+            raise ValueError("need an engine, an algo or a flow_fn")
+        self.algo, self.engine, self.flow_fn = algo, engine, flow_fn
+        self.iters, self.bgr, self.fuse_warp = int(iters), bool(bgr), bool(fuse_warp)
         self.warp_mode, self.thres, self.ksize, self.cmp_gt = warp_mode, thres, ksize, cmp_gt
 
-    def __call__(self, frames: torch.Tensor, key_raw: torch.Tensor, key_ai: torch.Tensor):
-        from . import ops
-        flow, conf = self.flow_fn(frames, key_raw)
-        warped, mask = ops.warp_and_mask(key_ai, flow, conf, warp_mode=self.warp_mode, thres=self.thres, ksize=self.ksize,
-                                         cmp_gt=self.cmp_gt)
+    def __call__(self, frames: torch.Tensor, key_raw: torch.Tensor, key_ai: torch.Tensor, confidence: Optional[torch.Tensor] = None):
+        """-> (flow f32[B,H,W,2] on each frame's grid pointing into the key frame, warped u8 [B,H,W,3], mask u8 [B,H,W])."""
+        flow, _, warped, mask = self.synthesize(frames, key_raw, key_ai, confidence)
         return flow, warped, mask
+
+    def synthesize(self, frames: torch.Tensor, key_raw: torch.Tensor, key_ai: torch.Tensor, confidence: Optional[torch.Tensor] = None):
+        """-> (flow, confidence f32[B,H,W], warped, mask)."""
+        from . import ops
+        H, W = frames.shape[-3], frames.shape[-2]
+        fuse = (self.fuse_warp and self.warp_mode == "bilinear" and self.flow_fn is None and key_ai.dim() == 3 and H % 8 == 0
+                and W % 8 == 0)
+        if self.flow_fn is not None:
+            flow, conf = self.flow_fn(frames, key_raw)
+            warped = None
+        elif confidence is not None and self.engine is not None:
+            conf = confidence
+            if fuse:
+                flow, warped = self.engine.forward(frames, key_raw, iters=self.iters, bgr=self.bgr, warp_frame=key_ai)
+            else:
+                flow, warped = self.engine.forward(frames, key_raw, iters=self.iters, bgr=self.bgr), None
+        elif self.algo is not None:
+            if fuse:
+                flow, conf, _, warped = self.algo.calc_batch_device(key_raw, frames, bgr=self.bgr, warp_frame=key_ai)
+            else:
+                (flow, conf, _), warped = self.algo.calc_batch_device(key_raw, frames, bgr=self.bgr), None
+            if confidence is not None:
+                conf = confidence
+        else:
+            raise ValueError("an engine-only FrameSynthesizer needs the confidence passed to the call")
+        if warped is not None:
+            mask = ops.generate_mask(conf.contiguous(), None, self.thres, self.ksize, cmp_gt=self.cmp_gt)
+        else:
+            warped, mask = ops.warp_and_mask(key_ai.contiguous(), flow.contiguous(), conf.contiguous(), warp_mode=self.warp_mode,
+                                             thres=self.thres, ksize=self.ksize, cmp_gt=self.cmp_gt)
+        return flow, conf, warped, mask
 
 
 def process_clip(frames: torch.Tensor, key_raw: torch.Tensor, key_ai: torch.Tensor, step: Callable, batch_size: int = 64,

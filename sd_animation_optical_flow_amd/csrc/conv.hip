@@ -1320,7 +1320,7 @@ extern "C" int ofx_conv2d_alpha(const ofx_conv_desc* d, float alpha, void* strea
     } else {
         auto waste = [&](int t) { return (double)(((d->Cout + t - 1) / t) * t) / d->Cout; };
         if (d->Cout <= 32) bn = 32;
-        else if (waste(128) <= 1.13) bn = 128;
+        else if (waste(128) <= 1.13 && !(waste(192) <= 1.0 && waste(128) > 1.05 && d->precision == OFX_PREC_FP32 && !d->nmean && d->epi == OFX_EPI_PLAIN)) bn = 128;   // (576 channels: 3 x 192, not 4.5 x 128)
         else if (waste(192) <= 1.05 && d->precision == OFX_PREC_FP32 && !d->nmean && d->epi != OFX_EPI_FLOW) bn = 192;   // 192-channel layers: one 128x192 tile instead of 128x64 x 3
         else if (waste(96) <= 1.05 && d->precision == OFX_PREC_FP32 && d->epi == OFX_EPI_PLAIN) bn = 96;   // 96-channel encoder stage
         else if (waste(64) <= 1.13) bn = 64;
@@ -1377,9 +1377,11 @@ extern "C" int ofx_conv2d_alpha(const ofx_conv_desc* d, float alpha, void* strea
     // chunk wins (+8..20 % at one 512x768 pair).  tile = BK*1e6 + BM*1e3 + BN overrides.
     const int tile_bk = (d->tile % 1000000000) / 1000000;
     const int bk = tile_bk ? tile_bk : ((bn == 32 || bm == 64) ? 32 : 16);
-    // uniform-K fast path: valid for both chunk widths when every channel count is a multiple of 32
+    // uniform-K fast path: every chunk of this launch's BK inside one tap and one segment (the 16-float flow rows of convf1 qualify
+    // with BK = 16; a caller-forced tile keeps the conservative multiple-of-32 rule)
     static const bool no_uk = getenv("OFX_CONV_NO_UK") != nullptr;
-    k.uk = (!no_uk && k.cin % 32 == 0 && (d->c1 == 0 || d->c0 % 32 == 0)) ? 1 : 0;
+    const int ukm = d->tile ? 32 : bk;
+    k.uk = (!no_uk && k.cin % ukm == 0 && (d->c1 == 0 || d->c0 % ukm == 0)) ? 1 : 0;
     // halo-patch kernel: stride-1 3x3 / 1x5 / 5x1, "same" padding, the map a whole number of 8x16 patches, whole 16-channel slabs
     static const bool no_patch = getenv("OFX_CONV_NO_PATCH") != nullptr;
     const bool shape_ok = (d->KH == 3 && d->KW == 3) || (d->KH == 1 && d->KW == 5) || (d->KH == 5 && d->KW == 1);

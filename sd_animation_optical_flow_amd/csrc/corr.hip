@@ -290,10 +290,16 @@ __global__ __launch_bounds__(256) void corr_lookup_blocked_kernel(const LookupBA
             wy[l] = sane ? (int)yf - r : -100000;
             const __amdgpu_buffer_rsrc_t rs =
                 __builtin_amdgcn_make_buffer_rsrc((void*)(a.pyr[l] + m * a.slice[l]), (short)0, (int)(a.slice[l] * 4), 0x00020000);
+            // last window row / column that carries weight: integer coordinates (the whole first iteration at level 0) need 9, not 10
+            const int ex = fx > 0.f ? 9 : 8, ey = fy > 0.f ? 9 : 8;
 #pragma unroll
             for (int rr = 0; rr < 2; ++rr) {
                 const int by = (wy[l] >> 2) + bj[rr], bx = (wx[l] >> 3) + bi[rr];
-                const bool ok = slot_ok[rr] && (unsigned)by < (unsigned)a.hb[l] && (unsigned)bx < (unsigned)a.wb[l];
+                // only the blocks the 10x10 window overlaps: ((wy & 3) + 9) / 4 + 1 block rows, ((wx & 7) + 9) / 8 + 1 block columns
+                // (3.25 x 2.125 of the 4 x 3 slots on average; round 3 fetched every in-range slot: 27.6 lines per pixel where 18.7 do).  The slots left out keep the zeros of the failed range check;
+                // no tap reads them.
+                const bool ok = slot_ok[rr] && bj[rr] <= (((wy[l] & 3) + ey) >> 2) && bi[rr] <= (((wx[l] & 7) + ex) >> 3) &&
+                                (unsigned)by < (unsigned)a.hb[l] && (unsigned)bx < (unsigned)a.wb[l];
                 const int voff = ((__mul24(by, a.wb[l]) + bx) << 7) + (part << 4);
                 v[l * 2 + rr] = __builtin_amdgcn_raw_buffer_load_b128(rs, ok ? voff : -1, 0, AUX);   // out of range -> zeros
             }

@@ -13,7 +13,7 @@ struct FlowHeadArgs {
     const float* bias;     // [2]
     float* coords1;        // [M][2]  (in/out)
     float* hx_flow;        // &hx[0][flow_off], row stride ldh: flow = coords1 - coords0
-    float* flow4;          // [M][4]
+    float* frows;          // [M][16]: per pixel the flow of its 7-wide row neighbourhood, (x-3 .. x+3) x (fx, fy), 2 zero floats
     int ldx, ldh, Kpad, h, w_, M;
 };
 
@@ -149,7 +149,13 @@ __global__ __launch_bounds__(256, 2) void flow_head_kernel(const FlowHeadArgs a)
             a.coords1[m * 2 + o] = c1;
             const float fl = c1 - (float)(o == 0 ? x : y);
             a.hx_flow[m * a.ldh + o] = fl;
-            a.flow4[m * 4 + o] = fl;
+            // convf1's operand (update.py:93, 7x7 on the 2-channel flow): pixel x' = x + d keeps the flow of x in slot 3 - d of its
+            // row, so that the 7x7 convolution runs as a 7x1 one over 16-float rows -- K = 7 * 16 = 112 with 98 real products where
+            // the NHWC gather of 4-float pixels needed 7 * 7 * 4 = 196 with half of them zeros.  Slots of neighbours outside the
+            // image are never written and keep the zeros of ofx_init_state (= the convolution's zero padding).
+#pragma unroll
+            for (int d = -3; d <= 3; ++d)
+                if ((unsigned)(x + d) < (unsigned)a.w_) a.frows[(m + d) * 16 + (3 - d) * 2 + o] = fl;
         }
     }
 }
@@ -157,9 +163,9 @@ __global__ __launch_bounds__(256, 2) void flow_head_kernel(const FlowHeadArgs a)
 }  // namespace
 
 int ofx_flow_head_launch(const float* x, int ldx, const float* w, int Kpad, const float* bias, float* coords1, float* hx_flow,
-                         int ldh, float* flow4, int B, int h, int w_, hipStream_t s) {
+                         int ldh, float* frows, int B, int h, int w_, hipStream_t s) {
     FlowHeadArgs a;
-    a.x = x; a.w = w; a.bias = bias; a.coords1 = coords1; a.hx_flow = hx_flow; a.flow4 = flow4;
+    a.x = x; a.w = w; a.bias = bias; a.coords1 = coords1; a.hx_flow = hx_flow; a.frows = frows;
     a.ldx = ldx; a.ldh = ldh; a.Kpad = Kpad; a.h = h; a.w_ = w_;
     const long M = (long)B * h * w_;
     OFX_REQUIRE(M * ldx * 4 < (1L << 31) - 64, OFX_EINVAL);      // 32-bit byte offsets into x

@@ -172,13 +172,16 @@ __global__ __launch_bounds__(256) void inorm_apply_kernel(const float* __restric
         const float4 v = make_float4(t.x, t.y, t.z, t.w);
         float4 y;
         y.x = (v.x - mu.x) * rs.x; y.y = (v.y - mu.y) * rs.y; y.z = (v.z - mu.z) * rs.z; y.w = (v.w - mu.w) * rs.w;
-        if (relu || ri) {
+        if ((relu & 1) || ri) {
             y.x = fmaxf(y.x, 0.f); y.y = fmaxf(y.y, 0.f); y.z = fmaxf(y.z, 0.f); y.w = fmaxf(y.w, 0.f);
         }
         if (ri) {
             float4 r = ri[i];
             if (rmean) {
                 r.x = (r.x - m2.x) * s2.x; r.y = (r.y - m2.y) * s2.y; r.z = (r.z - m2.z) * s2.z; r.w = (r.w - m2.w) * s2.w;
+                if (relu & 2) {   // the residual is itself relu(norm(raw)): the stem's output, never materialised (raft_engine.cpp)
+                    r.x = fmaxf(r.x, 0.f); r.y = fmaxf(r.y, 0.f); r.z = fmaxf(r.z, 0.f); r.w = fmaxf(r.w, 0.f);
+                }
             }
             y.x = fmaxf(r.x + y.x, 0.f); y.y = fmaxf(r.y + y.y, 0.f); y.z = fmaxf(r.z + y.z, 0.f); y.w = fmaxf(r.w + y.w, 0.f);
         }
@@ -193,14 +196,15 @@ __global__ __launch_bounds__(256) void upsample_kernel(const float* __restrict__
     if (o.valid) ofx_upsample_store(o, flow_up, h, w);
 }
 
-// coords1 = pixel grid, flow4 = 0, hx[:, flow_off:flow_off+2] = 0   (RAFT.initialize_flow, raft.py:63-70)
-__global__ __launch_bounds__(256) void init_state_kernel(float* __restrict__ coords1, float* __restrict__ flow4,
+// coords1 = pixel grid, frows (the flow rows convf1 reads, flow_head.hip) = 0, hx[:, flow_off:flow_off+2] = 0   (RAFT.initialize_flow, raft.py:63-70)
+__global__ __launch_bounds__(256) void init_state_kernel(float* __restrict__ coords1, float* __restrict__ frows,
                                                          float* __restrict__ hx, int ldh, int flow_off, int h, int w, long M) {
     for (long m = (long)blockIdx.x * blockDim.x + threadIdx.x; m < M; m += (long)gridDim.x * blockDim.x) {
         const int rem = (int)(m % ((long)h * w));
         const int y = rem / w, x = rem - y * w;
         reinterpret_cast<float2*>(coords1)[m] = make_float2((float)x, (float)y);
-        reinterpret_cast<float4*>(flow4)[m] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) reinterpret_cast<float4*>(frows)[m * 4 + q] = make_float4(0.f, 0.f, 0.f, 0.f);
         hx[m * ldh + flow_off] = 0.f;
         hx[m * ldh + flow_off + 1] = 0.f;
     }
@@ -218,11 +222,11 @@ __global__ __launch_bounds__(256) void coords_to_flow_kernel(const float* __rest
 
 }  // namespace
 
-int ofx_init_state(float* coords1, float* flow4, float* hx, int ldh, int flow_off, int B, int h, int w, hipStream_t s) {
+int ofx_init_state(float* coords1, float* frows, float* hx, int ldh, int flow_off, int B, int h, int w, hipStream_t s) {
     const long M = (long)B * h * w;
     OfxProfScope prof("init_state", s);
     hipLaunchKernelGGL(init_state_kernel, dim3((unsigned)std::min<long>((M + 255) / 256, 8192)), dim3(256), 0, s, coords1,
-                       flow4, hx, ldh, flow_off, h, w, M);
+                       frows, hx, ldh, flow_off, h, w, M);
     return ofx_launch_status();
 }
 

@@ -87,10 +87,10 @@ bool ofx_upsample_warp_ok(int B, int H, int W);
 int ofx_warp_pad_launch(const uint8_t* frame, void* pad, int H, int W, hipStream_t s);
 int ofx_upsample_warp_launch(const float* coords1, const float* mask, float* flow_up, const void* pad, uint8_t* warped, int B, int h, int w,
                              float sign, hipStream_t s);
-int ofx_init_state(float* coords1, float* flow4, float* hx, int ldh, int flow_off, int B, int h, int w, hipStream_t s);
+int ofx_init_state(float* coords1, float* frows, float* hx, int ldh, int flow_off, int B, int h, int w, hipStream_t s);
 int ofx_coords_to_flow(const float* coords1, float* flow, int B, int h, int w, hipStream_t s);
 int ofx_flow_head_launch(const float* x, int ldx, const float* w, int Kpad, const float* bias, float* coords1, float* hx_flow,
-                         int ldh, float* flow4, int B, int h, int w_, hipStream_t s);
+                         int ldh, float* frows, int B, int h, int w_, hipStream_t s);
 int ofx_ctx_gather(const float* ctx, const int* idx_dev, float* hx, int ldh, int off2, int half, int B, long N, hipStream_t s);
 
 // ---- device helpers --------------------------------------------------------------------

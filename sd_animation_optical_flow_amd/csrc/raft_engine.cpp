@@ -65,6 +65,7 @@ constexpr int MOT_OFF = HD;
 constexpr int FLOW_OFF = MOT_OFF + 126;
 constexpr int INP_OFF = HD + 128;
 constexpr int GADD_LD = 2 * (2 * HD + HD);   // [zr1(256) | q1(128) | zr2(256) | q2(128)]
+constexpr int FROW = 16;         // floats per flow row: 7 row neighbours x (fx, fy) + 2 zeros -- convf1's operand (flow_head.hip)
 constexpr int ENC_CHUNK = 64;          // images per encoder pass (bounds the activation workspace)
 // ... fewer for large frames: the widest encoder activation (64 channels at half resolution) must stay
 // below the 2 GiB reach of the convolution kernel's 32-bit byte offsets
@@ -415,11 +416,16 @@ static int run_encoder(ofx_raft* r, const std::string& enc, bool bn, const uint8
     };
     float* X = eb.X;
     float* Y = eb.Y;
+    // instance norm: the stem's normalised output is never materialised.  Its raw output stays in X with its statistics in (m3, s3)
+    // -- free until the first strided block -- and both of its consumers apply relu(norm(.)) on the fly: layer1.0.conv1 in its
+    // operand staging (like every conv2), layer1.0's residual merge inside its inorm_apply (relu bit 1).  One full-resolution
+    // read + write pass less per encoder.
+    bool stem_raw = false;
     if (!bn) {
         want_stats();
-        L.conv(C("conv1"), eb.x0, 4, 4, nullptr, 0, 0, eb.R1, 64, n, H, W, 2, OFX_ACT_NONE);
-        stats(eb.R1, (long)H2 * W2, 64, m1, s1, "norm1");
-        if (!L.st) L.st = ofx_inorm_apply(eb.R1, m1, s1, nullptr, nullptr, nullptr, X, n, (long)H2 * W2, 64, 1, s);
+        L.conv(C("conv1"), eb.x0, 4, 4, nullptr, 0, 0, X, 64, n, H, W, 2, OFX_ACT_NONE);
+        stats(X, (long)H2 * W2, 64, m3, s3, "norm1");
+        stem_raw = true;
     } else {
         L.conv(C("conv1"), eb.x0, 4, 4, nullptr, 0, 0, X, 64, n, H, W, 2, OFX_ACT_RELU);
     }
@@ -433,7 +439,8 @@ static int run_encoder(ofx_raft* r, const std::string& enc, bool bn, const uint8
             const std::string p = "layer" + std::to_string(li) + "." + std::to_string(bi);
             if (!bn) {
                 want_stats();
-                L.conv(C(p + ".conv1"), X, cin, cin, nullptr, 0, 0, eb.R1, dim, n, hin, win, stride, OFX_ACT_NONE);
+                L.conv(C(p + ".conv1"), X, cin, cin, nullptr, 0, 0, eb.R1, dim, n, hin, win, stride, OFX_ACT_NONE, OFX_EPI_PLAIN, nullptr, 0,
+                       stem_raw ? m3 : nullptr, stem_raw ? s3 : nullptr);
                 stats(eb.R1, (long)ho * wo, dim, m1, s1, p + ".norm1");
                 // norm1 + ReLU fused into conv2's operand load
                 want_stats();
@@ -446,8 +453,11 @@ static int run_encoder(ofx_raft* r, const std::string& enc, bool bn, const uint8
                     stats(eb.R3, (long)ho * wo, dim, m3, s3, p + ".norm3");
                     if (!L.st) L.st = ofx_inorm_apply(eb.R2, m2, s2, eb.R3, m3, s3, Y, n, (long)ho * wo, dim, 1, s);
                 } else {
-                    if (!L.st) L.st = ofx_inorm_apply(eb.R2, m2, s2, X, nullptr, nullptr, Y, n, (long)ho * wo, dim, 1, s);
+                    if (!L.st)
+                        L.st = ofx_inorm_apply(eb.R2, m2, s2, X, stem_raw ? m3 : nullptr, stem_raw ? s3 : nullptr, Y, n, (long)ho * wo, dim,
+                                               stem_raw ? 3 : 1, s);
                 }
+                stem_raw = false;
             } else {
                 L.conv(C(p + ".conv1"), X, cin, cin, nullptr, 0, 0, eb.R1, dim, n, hin, win, stride, OFX_ACT_RELU);
                 const float* res = X;
@@ -484,7 +494,7 @@ struct RaftWs {
     float* ctx;       // indexed-pairs mode: per-image context features [n][N][256] (tanh | relu halves)
     int* idx_dev;     // indexed-pairs mode: image1 index per pair
     float* pyr[LEVELS];
-    float *hx, *gadd, *coords1, *flow4, *corr, *c1, *corflo, *f1, *z, *rh, *mask;
+    float *hx, *gadd, *coords1, *frows, *corr, *c1, *corflo, *f1, *z, *rh, *mask;
     void* warp_pad;   // zero-bordered RGBX copy of the frame the tail warps (ofx_raft_forward_warp)
     size_t bytes;
 };
@@ -539,7 +549,7 @@ static RaftWs carve(void* base, size_t cap, int B, int H, int W, int flags, int 
     w.hx = c.take((size_t)M * HX_LD);
     w.gadd = c.take((size_t)M * GADD_LD);
     w.coords1 = c.take((size_t)M * 2);
-    w.flow4 = c.take((size_t)M * 4);
+    w.frows = c.take((size_t)M * FROW);
     w.corr = c.take((size_t)M * CORR_CH);
     w.c1 = c.take((size_t)M * 256);
     w.corflo = c.take((size_t)M * 256);
@@ -556,11 +566,11 @@ static RaftWs carve(void* base, size_t cap, int B, int H, int W, int flags, int 
 // GRU terms, `iters` refinement iterations, mask head, convex upsample
 static int run_recurrence(ofx_raft* r, const RaftWs& ws, int B, int h, int w, int iters, bool alt, bool shared,
                           float* flow_up, float* flow_low, hipStream_t s, int precision, bool overlap, bool want_fused_lookup,
-                          uint8_t* warped = nullptr, float warp_sign = 1.0f) {
+                          uint8_t* warped = nullptr, float warp_sign = 1.0f, int n_warp = -1) {
     const long N = (long)h * w;
     const bool sh1 = shared, sh2 = shared;
     int st = 0;
-    st = ofx_init_state(ws.coords1, ws.flow4, ws.hx, HX_LD, FLOW_OFF, B, h, w, s);
+    st = ofx_init_state(ws.coords1, ws.frows, ws.hx, HX_LD, FLOW_OFF, B, h, w, s);
     if (st) return st;
     {   // loop-invariant GRU terms: conv(W[:, inp], inp) + bias for z|r and q of both passes
         Launcher G{s};
@@ -593,7 +603,7 @@ static int run_recurrence(ofx_raft* r, const RaftWs& ws, int B, int h, int w, in
     for (int it = 0; it < iters && !L.st; ++it) {
         // flow features (update.py:93-94) on the side stream, from the flow the previous iteration left
         if ((L.st = S.fork(0))) break;
-        LF.conv(C("convf1"), ws.flow4, 4, 4, nullptr, 0, 0, ws.f1, 128, B, h, w, 1, OFX_ACT_RELU);
+        LF.conv(C("convf1"), ws.frows, FROW, FROW, nullptr, 0, 0, ws.f1, 128, B, h, w, 1, OFX_ACT_RELU);   // 7x1 over the flow rows
         LF.conv(C("convf2"), ws.f1, 128, 128, nullptr, 0, 0, ws.corflo + 192, 256, B, h, w, 1, OFX_ACT_RELU);
         if ((L.st = LF.st)) break;
         // correlation features at the current estimate
@@ -632,7 +642,7 @@ static int run_recurrence(ofx_raft* r, const RaftWs& ws, int B, int h, int w, in
         L.conv(C("fh1"), ws.hx, HX_LD, HD, nullptr, 0, 0, ws.c1, 256, B, h, w, 1, OFX_ACT_RELU);
         if (!L.st) {   // 256 -> 2 channels: dedicated reduction kernel instead of a 1/16-utilised GEMM tile
             const ConvW& f2 = C("fh2");
-            L.st = ofx_flow_head_launch(ws.c1, 256, f2.w, (int)f2.kpad, f2.shift, ws.coords1, ws.hx + FLOW_OFF, HX_LD, ws.flow4, B, h,
+            L.st = ofx_flow_head_launch(ws.c1, 256, f2.w, (int)f2.kpad, f2.shift, ws.coords1, ws.hx + FLOW_OFF, HX_LD, ws.frows, B, h,
                                         w, s);
         }
     }
@@ -642,8 +652,14 @@ static int run_recurrence(ofx_raft* r, const RaftWs& ws, int B, int h, int w, in
     if (L.st) return L.st;
     // convex upsample -- with the backward warp of the AI key frame in the same pass when the caller asked for it: the flow is in
     // registers right there, flow_up is then written only if wanted
-    if (warped) st = ofx_upsample_warp_launch(ws.coords1, ws.mask, flow_up, ws.warp_pad, warped, B, h, w, warp_sign, s);
-    else st = ofx_upsample_flow(ws.coords1, ws.mask, flow_up, B, h, w, s);
+    // (n_warp: only the first n_warp pairs are warped -- the indexed-pairs call of the forward-backward confidence, whose reverse
+    // flows need no warp; the rest take the plain upsample)
+    const int nw = warped ? (n_warp < 0 ? B : std::min(n_warp, B)) : 0;
+    if (nw > 0) st = ofx_upsample_warp_launch(ws.coords1, ws.mask, flow_up, ws.warp_pad, warped, nw, h, w, warp_sign, s);
+    if (!st && nw < B) {
+        if (!flow_up) return OFX_EINVAL;
+        st = ofx_upsample_flow(ws.coords1 + (long)nw * N * 2, ws.mask + (long)nw * N * 576, flow_up + (long)nw * N * 128, B - nw, h, w, s);
+    }
     if (st) return st;
     if (flow_low) {
         st = ofx_coords_to_flow(ws.coords1, flow_low, B, h, w, s);
@@ -689,7 +705,29 @@ int ofx_raft_create(const ofx_tensor* tensors, int n, ofx_raft** out) {
         }
     }
     if (!st) st = add_conv(r, sd, std::string(ub) + "encoder.convc2", "convc2", 0, "", 1.f);
-    if (!st) st = add_conv(r, sd, std::string(ub) + "encoder.convf1", "convf1", 4, "", 1.f);
+    std::vector<float> wf1;   // must outlive add_conv below
+    if (!st) {
+        // convf1 (7x7 on the 2-channel flow, update.py:93) as a 7x1 convolution over the 16-float flow rows the flow head leaves
+        // (flow_head.hip): row channel kx * 2 + c = tap kx of input channel c, channels 14 and 15 are zero.  K = 112 instead of 196.
+        const HostTensor* wf = find(sd, std::string(ub) + "encoder.convf1.weight");
+        const HostTensor* bf = find(sd, std::string(ub) + "encoder.convf1.bias");
+        if (!wf || !bf || wf->ndim != 4 || wf->shape[1] != 2 || wf->shape[2] != 7 || wf->shape[3] != 7) st = OFX_EKEY;
+        if (!st) {
+            const int co = (int)wf->shape[0];
+            wf1.assign((size_t)co * 14 * 7, 0.f);
+            for (int o = 0; o < co; ++o)
+                for (int c = 0; c < 2; ++c)
+                    for (int ky = 0; ky < 7; ++ky)
+                        for (int kx = 0; kx < 7; ++kx)
+                            wf1[((size_t)o * 14 + kx * 2 + c) * 7 + ky] = wf->data[(((size_t)o * 2 + c) * 7 + ky) * 7 + kx];
+            HostTensor t;
+            t.data = wf1.data(); t.ndim = 4;
+            t.shape[0] = co; t.shape[1] = 14; t.shape[2] = 7; t.shape[3] = 1;
+            sd["convf1_rows.weight"] = t;
+            sd["convf1_rows.bias"] = *bf;
+            st = add_conv(r, sd, "convf1_rows", "convf1", FROW, "", 1.f);
+        }
+    }
     if (!st) st = add_conv(r, sd, std::string(ub) + "encoder.convf2", "convf2", 0, "", 1.f);
     if (!st) st = add_conv(r, sd, std::string(ub) + "encoder.conv", "conv", 0, "", 1.f);
     if (!st) st = build_gru(r, sd, "1");
@@ -881,7 +919,18 @@ size_t ofx_raft_workspace_bytes_pairs(const ofx_raft* r, int n_images, int B, in
 int ofx_raft_forward_pairs(ofx_raft* r, const uint8_t* images, int n_images, const int* idx1, const int* idx2, int B, int H,
                            int W, int iters, int flags, float* flow_up, float* flow_low, void* workspace,
                            size_t workspace_bytes, void* stream) {
+    return ofx_raft_forward_pairs_warp(r, images, n_images, idx1, idx2, B, H, W, iters, flags, flow_up, flow_low, nullptr, 1.0f, 0, nullptr,
+                                       workspace, workspace_bytes, stream);
+}
+
+int ofx_raft_forward_pairs_warp(ofx_raft* r, const uint8_t* images, int n_images, const int* idx1, const int* idx2, int B, int H,
+                                int W, int iters, int flags, float* flow_up, float* flow_low, const uint8_t* warp_frame, float warp_sign,
+                                int n_warp, uint8_t* warped, void* workspace, size_t workspace_bytes, void* stream) {
     OFX_REQUIRE(r && images && idx1 && idx2 && flow_up && workspace, OFX_EINVAL);
+    if (warped || warp_frame || n_warp) {
+        OFX_REQUIRE(warp_frame && warped && n_warp > 0 && n_warp <= B && (warp_sign == 1.0f || warp_sign == -1.0f), OFX_EINVAL);
+        OFX_REQUIRE(ofx_upsample_warp_ok(n_warp, H, W) && (((uintptr_t)warped) & 3u) == 0, OFX_EINVAL);
+    }
     OFX_REQUIRE(n_images > 0 && B > 0 && H >= 64 && W >= 64 && (H % 8) == 0 && (W % 8) == 0 && iters >= 1, OFX_EINVAL);
     OFX_REQUIRE(!(flags & (OFX_RAFT_ALT_CORR | OFX_RAFT_SHARED_IMG1 | OFX_RAFT_SHARED_IMG2)), OFX_EINVAL);
     OFX_REQUIRE((((uintptr_t)workspace) & 255u) == 0, OFX_EALIGN);
@@ -946,7 +995,12 @@ int ofx_raft_forward_pairs(ofx_raft* r, const uint8_t* images, int n_images, con
     }
     if (!st) st = ofx_corr_pool_launch(ws.pyr[0], ws.pyr[1], ws.pyr[2], ws.pyr[3], B, h, w, LEVELS, s, fused_pairs);
     if (st) return st;
-    st = run_recurrence(r, ws, B, h, w, iters, false, false, flow_up, flow_low, s, prec, overlap, flags & OFX_RAFT_FUSED_LOOKUP);
+    if (warped) {   // the zero-bordered RGBX copy the warp samples
+        st = ofx_warp_pad_launch(warp_frame, ws.warp_pad, H, W, s);
+        if (st) return st;
+    }
+    st = run_recurrence(r, ws, B, h, w, iters, false, false, flow_up, flow_low, s, prec, overlap, flags & OFX_RAFT_FUSED_LOOKUP, warped, warp_sign,
+                        n_warp);
     if (st) return st;
     r->bufs.clear();
     return 0;

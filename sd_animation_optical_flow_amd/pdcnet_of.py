@@ -61,15 +61,33 @@ class PDCNetPlus:
     # ---- device-resident core ------------------------------------------------------------------
     @torch.no_grad()
     def calc_batch_device(self, source: torch.Tensor, target: torch.Tensor, bgr: bool = False,
-                          want_confidence: bool = True):
+                          want_confidence: bool = True, warp_frame: Optional[torch.Tensor] = None):
         """source/target: uint8 [B,H,W,3] on the device (`source` may be a single [H,W,3] key frame shared
         by the batch).  Returns (flow f32[B,H,W,2] on the target grid pointing into source, confidence
-        f32[B,H,W], log_confidence f32[B,H,W]) -- all on the device."""
+        f32[B,H,W], log_confidence f32[B,H,W]) -- all on the device.
+        warp_frame: uint8 [H,W,3] on the device (the rendered AI key frame, shared by the batch): a fourth result is appended,
+        `warp_frame` warped backward along each flow with bilinear taps (`warp_frame(ai, flow)` of pdcnet_of.py:34-42 in the
+        north star's bilinear mode), u8 [B,H,W,3].  On frames whose sides are multiples of 8 it comes out of the convex
+        upsample itself (`ofx_raft_forward_warp` / `ofx_raft_forward_pairs_warp`: the flow is never re-read), bit-identical to
+        `ops.warp(warp_frame, flow, 'bilinear')`, which padded frames fall back to."""
         net = self.network
         H0, W0 = target.shape[-3], target.shape[-2]
+        fuse = warp_frame is not None and H0 % 8 == 0 and W0 % 8 == 0
+        if warp_frame is not None and (not warp_frame.is_cuda or warp_frame.dtype != torch.uint8 or tuple(warp_frame.shape) != (H0, W0, 3)):
+            raise RuntimeError(f"warp_frame must be a CUDA uint8 tensor [{H0},{W0},3]")
+
+        def done(flow, conf, logc, warped=None):
+            if warp_frame is None:
+                return flow, conf, logc
+            if warped is None:                                 # padded frame: the warp runs on the cropped flow, as the reference's would
+                warped = ops.warp(warp_frame.contiguous(), flow.contiguous(), mode="bilinear", sign=1.0)
+            return flow, conf, logc, warped
         if not want_confidence:
+            if fuse:
+                flow, warped = net.forward(target, source, iters=self.iters, bgr=bgr, warp_frame=warp_frame)   # target -> source
+                return done(flow, None, None, warped)
             flow = net.forward(target, source, iters=self.iters, bgr=bgr)                      # target -> source
-            return _unpad(flow, H0, W0), None, None
+            return done(_unpad(flow, H0, W0), None, None)
         # Both directions in ONE indexed-pairs call: every image is encoded once (two separate forwards encode each
         # image twice) and the forward / backward refinements share their launches (2B pairs per batch).
         shared = source.dim() == 3
@@ -79,14 +97,19 @@ class PDCNetPlus:
         if not shared and ns != B:
             raise RuntimeError("source / target batch sizes differ")
         step = max(1, net.max_pairs(tgt.shape[1], tgt.shape[2]) // 2)
-        fts, fss = [], []
+        fts, fss, wps = [], [], []
         for b0 in range(0, B, step):
             t = tgt[b0:b0 + step]
             s = src if shared else src[b0:b0 + step]
             n, m = t.shape[0], s.shape[0]
             it = [m + i for i in range(n)]                     # image index of target i in cat([s, t])
             isrc = [0] * n if shared else list(range(n))
-            out = net.forward_pairs(torch.cat([s, t]), it + isrc, isrc + it, iters=self.iters, bgr=bgr)
+            if fuse:                                           # the first n pairs (target -> source) are the ones the AI frame rides on
+                out, wp = net.forward_pairs(torch.cat([s, t]), it + isrc, isrc + it, iters=self.iters, bgr=bgr, warp_frame=warp_frame,
+                                            n_warp=n)
+                wps.append(wp)
+            else:
+                out = net.forward_pairs(torch.cat([s, t]), it + isrc, isrc + it, iters=self.iters, bgr=bgr)
             fts.append(out[:n])                                # on the target grid, pointing into the source
             fss.append(out[n:])                                # on the source grid, pointing into the target
         flow_t = fts[0] if len(fts) == 1 else torch.cat(fts)
@@ -94,7 +117,8 @@ class PDCNetPlus:
         # the consistency check runs on the padded grids (both flows live there); the reference's `calc` promises
         # [H,W] outputs (pdcnet_of.py:72-75), so the replicate padding is cropped away afterwards
         conf, logc = ops.fb_confidence(flow_t.contiguous(), flow_s.contiguous(), self.sigma)
-        return _unpad(flow_t, H0, W0), _unpad(conf, H0, W0), _unpad(logc, H0, W0)
+        warped = (wps[0] if len(wps) == 1 else torch.cat(wps)) if fuse else None
+        return done(_unpad(flow_t, H0, W0), _unpad(conf, H0, W0), _unpad(logc, H0, W0), warped)
 
     @torch.no_grad()
     def calc_pairs(self, frames: torch.Tensor, pairs, bgr: bool = False, max_flows: int = 64):

@@ -45,15 +45,23 @@ class ClipPipeline:
     """`algo`: a `pdcnet_of.PDCNetPlus`; `vae`: optional `vae.VaeEncoder`; `render(packet, raw_bgr) -> u8 [H,W,3]` turns a
     packet into the AI frame (default: `_paste_raw`); key frames are rendered by `render_key(raw_bgr) -> u8 [H,W,3]`
     (default: identity).  `batch` frames share one executor call per key frame.  Rank-aware: under an initialised
-    `torch.distributed` group every rank runs the same `run(video)` and takes its share (`packets`)."""
+    `torch.distributed` group every rank runs the same `run(video)` and takes its share (`packets`).  `io_threads` / `prefetch`: the
+    asynchronous host side (`hostio.FrameLoader` / `FrameWriter`); the output is byte-identical with it off (`io_threads=0`)."""
 
     def __init__(self, algo, vae=None, render: Optional[Callable] = None, render_key: Optional[Callable] = None, batch: int = 64,
-                 warp_mode: str = "bilinear", thres: float = 0.95, ksize: int = 7, mask_blur: float = 4.0, device=None):
+                 warp_mode: str = "bilinear", thres: float = 0.95, ksize: int = 7, mask_blur: float = 4.0, device=None,
+                 io_threads: int = 4, prefetch: int = 2):
         self.algo, self.vae = algo, vae
         self.render = render or _paste_raw
         self.render_key = render_key or (lambda raw: raw)
         self.batch, self.warp_mode, self.thres, self.ksize, self.mask_blur = int(batch), warp_mode, float(thres), int(ksize), float(mask_blur)
         self.device = device if device is not None else algo.device
+        # host side (hostio.py): PNG decode / encode on `io_threads` workers each, `prefetch` batches decoded ahead of the GPU;
+        # io_threads = 0 runs all of it inline on the calling thread (the reference's behaviour)
+        self.io_threads, self.prefetch = max(0, int(io_threads)), max(1, int(prefetch))
+        # the compute step is the same object bench.py times: with the bilinear warp the AI key frame is warped inside the flow
+        # network's convex upsample (one kernel), the cubic modes take upsample -> ofx_warp_and_mask
+        self.synth = clip.FrameSynthesizer(algo, warp_mode=warp_mode, thres=self.thres, ksize=self.ksize, bgr=True) if algo is not None else None
 
     def key_frame_flags(self, video, th: float = 8.5) -> List[bool]:
         """One flag per WORKSPACE frame (flags[i] belongs to `video.get_raw_frame(i)`).  The workspace is already decimated
@@ -71,9 +79,7 @@ class ClipPipeline:
         """flow + confidence -> warp + mask -> SD-inpaint inputs for `raws` (u8 [b,H,W,3] BGR, device) against one key frame;
         returns the packets.  The one compute step of the pipeline (tests of the rank logic substitute it on the CPU)."""
         # source = key frame, target = frames: flow on each frame's grid pointing into the key frame (BGR in)
-        flow, conf, _ = self.algo.calc_batch_device(key_raw, raws, bgr=True)
-        warped, mask = ops.warp_and_mask(key_ai.contiguous(), flow.contiguous(), conf.contiguous(), warp_mode=self.warp_mode,
-                                         thres=self.thres, ksize=self.ksize)
+        flow, conf, warped, mask = self.synth.synthesize(raws, key_raw, key_ai.contiguous())
         inp = handoff.prepare_inpaint_inputs(warped, raws, mask, mask_blur=self.mask_blur, device=self.device)
         if self.vae is not None:
             inp["init_latent"] = self.vae.get_first_stage_encoding(inp["image"])
@@ -81,43 +87,94 @@ class ClipPipeline:
                 for k, t in enumerate(ids)]
 
     @torch.no_grad()
-    def packets(self, video, flags: List[bool]):
+    def packets(self, video, flags: List[bool], writer=None):
         """Yields (FramePacket | None, raw_bgr tensor, index) for THIS rank's share of the clip: None for the key frames this
         rank renders.  One process: everything.  Under `torch.distributed` (one process per GPU): `clip.plan_segments` spreads
         the key-frame segments over the ranks; the rank that owns a segment renders its key frame, and only when a segment had
         to be cut does the rendered key frame travel -- one `broadcast_keyframe` (RCCL on the `nccl` backend), the single
-        collective of the path.  Raw frames come from the workspace, which the ranks of a node share."""
+        collective of the path.  Raw frames come from the workspace, which the ranks of a node share.
+        Host side (`hostio.FrameLoader`): the PNGs of the next `prefetch` batches are decoded on a thread pool into pinned
+        buffers while the current batch's kernels run, and uploaded on a copy stream.  `writer`: where rendered key frames go
+        (`run` passes its asynchronous `hostio.FrameWriter`; default: synchronous `video.put_ai_frame`)."""
+        from . import hostio
         rank, world = clip.dist_info()
-        for seg in clip.plan_segments(flags, world):
+        # this rank's load units, in the order they are consumed: (segment, 'key' | list of frame ids)
+        units = []
+        plans = clip.plan_segments(flags, world)
+        for seg in plans:
             mine = seg.frames[rank]
             owner = rank == seg.owner
             if not (owner or mine or seg.needs_broadcast):
                 continue
-            shape = (*video.size_hw, 3)
-            key_raw = torch.from_numpy(video.get_raw_frame(seg.key)).to(self.device) if (owner or mine) else None
-            if owner:
-                key_ai = self.render_key(key_raw).contiguous()
-                video.put_ai_frame(seg.key, key_ai.cpu().numpy())
-                yield None, key_raw, seg.key
-            else:
-                key_ai = torch.empty(shape, dtype=torch.uint8, device=self.device)
-            if seg.needs_broadcast:
-                # the one collective of the path; every rank of the group takes part, also those with no frame of this segment
-                clip.broadcast_keyframe([key_ai], src=seg.owner)
+            units.append((seg, "key" if (owner or mine) else None))
             for b0 in range(0, len(mine), self.batch):
-                ids = mine[b0:b0 + self.batch]
-                raws = torch.from_numpy(np.stack([video.get_raw_frame(t) for t in ids])).to(self.device)
+                units.append((seg, mine[b0:b0 + self.batch]))
+        loader = hostio.FrameLoader(video, self.device, threads=self.io_threads, slots=self.prefetch + 1, batch=self.batch)
+        tickets = {}
+
+        def ahead(k: int) -> None:
+            for j in range(k, min(len(units), k + 1 + self.prefetch)):
+                if j not in tickets and units[j][1] is not None:
+                    what = units[j][1]
+                    tickets[j] = loader.request([units[j][0].key] if what == "key" else what)
+        try:
+            key_raw = key_ai = None
+            for k, (seg, what) in enumerate(units):
+                ahead(k)
+                if what is None or what == "key":
+                    owner = rank == seg.owner
+                    shape = (*video.size_hw, 3)
+                    key_raw = loader.fetch(tickets.pop(k))[0] if what == "key" else None
+                    if owner:
+                        key_ai = self.render_key(key_raw).contiguous()
+                        if writer is not None:
+                            writer.put(seg.key, key_ai)
+                        else:
+                            video.put_ai_frame(seg.key, key_ai.cpu().numpy())
+                        yield None, key_raw, seg.key
+                    else:
+                        key_ai = torch.empty(shape, dtype=torch.uint8, device=self.device)
+                    if seg.needs_broadcast:
+                        # the one collective of the path; every rank of the group takes part, also those with no frame of this segment
+                        clip.broadcast_keyframe([key_ai], src=seg.owner)
+                    continue
+                ids = what
+                raws = loader.fetch(tickets.pop(k))
                 for pkt, raw in zip(self.process_batch(key_raw, key_ai, raws, ids, seg.key), raws):
                     yield pkt, raw, pkt.index
+        finally:
+            loader.close()
+
+    def shared_flags(self, video, th: float = 8.5) -> List[bool]:
+        """Key-frame flags every rank agrees on: rank 0 runs the detector and broadcasts its decisions (one byte per frame).  Each
+        rank deriving them for itself would repeat the detection world-size times and -- should two ranks ever disagree on one
+        frame (another GPU, driver or library build) -- issue different broadcast sequences and hang without a diagnostic."""
+        rank, world = clip.dist_info()
+        if world == 1:
+            return self.key_frame_flags(video, th)
+        import torch.distributed as dist
+        n = video.num_frames
+        t = torch.zeros((n,), dtype=torch.uint8, device=self.device)
+        if rank == 0:
+            t.copy_(torch.tensor(self.key_frame_flags(video, th), dtype=torch.uint8))
+        dist.broadcast(t, src=0)
+        return [bool(v) for v in t.cpu().tolist()]
 
     def run(self, video, flags: Optional[List[bool]] = None) -> List[int]:
         """Processes this rank's share of the workspace (all of it in one process); writes `ai-frames/{n:05d}.png` for the frames
-        it owns -- results stay with the owning rank; returns the key-frame indices this rank rendered."""
-        flags = flags if flags is not None else self.key_frame_flags(video)
+        it owns -- results stay with the owning rank; returns the key-frame indices this rank rendered.  Rendered frames leave
+        through `hostio.FrameWriter`: D2H into pinned memory on a side stream, PNG encoding on worker threads, one `flush()` at
+        the end (every file is on disk when `run` returns)."""
+        from . import hostio
+        flags = flags if flags is not None else self.shared_flags(video)
+        writer = hostio.FrameWriter(video, self.device, threads=self.io_threads)
         keys = []
-        for pkt, raw, idx in self.packets(video, flags):
-            if pkt is None:
-                keys.append(idx)
-                continue
-            video.put_ai_frame(idx, self.render(pkt, raw).cpu().numpy())
+        try:
+            for pkt, raw, idx in self.packets(video, flags, writer=writer):
+                if pkt is None:
+                    keys.append(idx)
+                    continue
+                writer.put(idx, self.render(pkt, raw))
+        finally:
+            writer.close()                                   # flush: joins the encoders, re-raises their first failure
         return keys

@@ -24,7 +24,11 @@ PRECISIONS = {"fp32": 0, "bf16x3": FLAG_BF16X3, "bf16x6": FLAG_BF16X6}
 class RaftEngine:
     def __init__(self, state_dict: Dict[str, torch.Tensor], device: Optional[torch.device] = None, precision: str = "fp32",
                  cnet_norm: str = "eval"):
-        """cnet_norm: how the context encoder's BatchNorm layers (RAFT/core/raft.py:55) are evaluated.  'eval' (default):
+        """NOTE THE DEFAULT SPLIT: `RaftEngine` (and the `pdcnet_of` surface built on it) defaults to cnet_norm='eval'; `ofgen.RAFT_2`
+        -- the reference's RAFT wrapper AS WRITTEN -- passes cnet_norm='batch'.  The two networks differ by more than 1 px of flow:
+        build the engine with cnet_norm='batch' to mirror `RAFT_2`.
+
+        cnet_norm: how the context encoder's BatchNorm layers (RAFT/core/raft.py:55) are evaluated.  'eval' (default):
         with their running statistics, folded into the convolutions -- a model in `.eval()`, what PDCNet's own code does
         (pdcnet_of.py:62) and canonical RAFT inference.  'batch': with the statistics of the image itself -- the
         reference's `RAFT_2` AS WRITTEN, which never calls `.eval()` (ofgen_keyframe_inpaint.py:47-60) and feeds one image
@@ -182,10 +186,14 @@ class RaftEngine:
         return (flow_up, flow_low, warped) if want_low else (flow_up, warped)
 
     @torch.no_grad()
-    def forward_pairs(self, images: torch.Tensor, idx1, idx2, iters: int = 20, bgr: bool = False) -> torch.Tensor:
+    def forward_pairs(self, images: torch.Tensor, idx1, idx2, iters: int = 20, bgr: bool = False,
+                      warp_frame: Optional[torch.Tensor] = None, warp_sign: float = 1.0, n_warp: int = 0):
         """images: uint8 [n,H,W,3] on the device (H, W multiples of 8); pair b = (idx1[b], idx2[b]):
         flow b lives on image idx1[b] and points into image idx2[b].  Every image is encoded once however
-        many pairs use it (KeyframeConv's N x N sweep).  Returns f32 [B,H,W,2] on the device."""
+        many pairs use it (KeyframeConv's N x N sweep).  Returns f32 [B,H,W,2] on the device.
+        warp_frame (uint8 [H,W,3], one frame shared by the batch) + n_warp: the first n_warp pairs also get the bilinear
+        backward warp of warp_frame along their final flow, produced inside the convex upsample
+        (`ofx_raft_forward_pairs_warp`); returns (flow, warped u8 [n_warp,H,W,3])."""
         if not images.is_cuda or images.dtype != torch.uint8 or images.dim() != 4 or images.shape[3] != 3:
             raise RuntimeError("images must be a CUDA uint8 tensor [n,H,W,3]")
         imgs = images.contiguous()
@@ -206,11 +214,26 @@ class RaftEngine:
             self._ws = torch.empty((need,), dtype=torch.uint8, device=self.device)
         flow_up = torch.empty((B, H, W, 2), dtype=torch.float32, device=self.device)
         stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-        check(L.ofx_raft_forward_pairs(self._h, C.c_void_p(imgs.data_ptr()), n, a1, a2, B, H, W, int(iters),
-                                       (FLAG_BGR if bgr else 0) | PRECISIONS[self.precision] | CNET_NORMS[self.cnet_norm],
-                                       C.c_void_p(flow_up.data_ptr()), None,
-                                       C.c_void_p(self._ws.data_ptr()), self._ws.numel(), stream), "ofx_raft_forward_pairs")
-        return flow_up
+        flags = (FLAG_BGR if bgr else 0) | PRECISIONS[self.precision] | CNET_NORMS[self.cnet_norm]
+        if warp_frame is None:
+            check(L.ofx_raft_forward_pairs(self._h, C.c_void_p(imgs.data_ptr()), n, a1, a2, B, H, W, int(iters), flags,
+                                           C.c_void_p(flow_up.data_ptr()), None,
+                                           C.c_void_p(self._ws.data_ptr()), self._ws.numel(), stream), "ofx_raft_forward_pairs")
+            return flow_up
+        if not warp_frame.is_cuda or warp_frame.dtype != torch.uint8 or tuple(warp_frame.shape) != (H, W, 3):
+            raise RuntimeError(f"warp_frame must be a CUDA uint8 tensor [{H},{W},3]")
+        if warp_sign not in (1.0, -1.0):
+            raise ValueError("warp_sign must be +1 or -1")
+        n_warp = int(n_warp)
+        if not 0 < n_warp <= B:
+            raise ValueError("n_warp must be in 1..B")
+        wf = warp_frame.contiguous()
+        warped = torch.empty((n_warp, H, W, 3), dtype=torch.uint8, device=self.device)
+        check(L.ofx_raft_forward_pairs_warp(self._h, C.c_void_p(imgs.data_ptr()), n, a1, a2, B, H, W, int(iters), flags,
+                                            C.c_void_p(flow_up.data_ptr()), None, C.c_void_p(wf.data_ptr()), float(warp_sign), n_warp,
+                                            C.c_void_p(warped.data_ptr()), C.c_void_p(self._ws.data_ptr()), self._ws.numel(), stream),
+              "ofx_raft_forward_pairs_warp")
+        return flow_up, warped
 
     def buffer(self, name: str) -> torch.Tensor:
         """Copy of a named intermediate of the last forward (flat f32) -- for stage-level parity tests."""

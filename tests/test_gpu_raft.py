@@ -262,8 +262,11 @@ def test_bench_workload_c3_b64_20iters_512x768(engine, raft_sd):
     from sd_animation_optical_flow_amd import ops
     B, H, W = 64, bench.H, bench.W
     frames, key, key_ai, conf = bench.make_clip(B, H, W, torch.device("cuda"))
-    flow = engine.forward(frames, key, iters=bench.ITERS)
+    # THE step bench.py times (bench.make_step: clip.FrameSynthesizer over the engine, the AI key frame warped inside the convex
+    # upsample, then the mask) -- flow, warped and mask below all come out of it
+    flow, warped, mask = bench.make_step(engine, frames, key, key_ai, conf)()
     assert tuple(flow.shape) == (B, H, W, 2) and torch.isfinite(flow).all()
+    assert tuple(warped.shape) == (B, H, W, 3) and tuple(mask.shape) == (B, H, W)
     kf = key.cpu().permute(2, 0, 1)[None].float()
     for b in (0, 31, 63):
         _, up = RO.raft_forward(raft_sd, frames[b].cpu().permute(2, 0, 1)[None].float(), kf, iters=bench.ITERS)
@@ -274,7 +277,9 @@ def test_bench_workload_c3_b64_20iters_512x768(engine, raft_sd):
         single = engine.forward(frames[b:b + 1], key, iters=bench.ITERS)
         worst = max(worst, (flow[b:b + 1] - single).abs().max().item())
     assert worst < 2e-3, worst                         # 20 recurrent fp32 iterations, different tile schedules
-    warped, mask = ops.warp_and_mask(key_ai, flow, conf, warp_mode="bilinear", thres=0.95, ksize=7)
+    # the two-kernel tail (upsample, then ofx_warp_and_mask) must give the same bytes as the fused one
+    warped2, mask2 = ops.warp_and_mask(key_ai, flow, conf, warp_mode="bilinear", thres=0.95, ksize=7)
+    assert torch.equal(warped2, warped) and torch.equal(mask2, mask)
     for b in (0, 31, 63):
         ref_w = warp_oracle.warp_frame(key_ai.cpu().numpy(), flow[b].cpu().numpy(), mode="bilinear")
         d = np.abs(warped[b].cpu().numpy().astype(np.int32) - ref_w.astype(np.int32))
@@ -282,6 +287,26 @@ def test_bench_workload_c3_b64_20iters_512x768(engine, raft_sd):
         c = conf[b].cpu().numpy()
         ref_m, _ = mask_oracle.generate_mask(c, c.copy(), 0.95, 7)
         assert np.array_equal(mask[b].cpu().numpy(), ref_m)
+
+
+def test_raft2_as_written_at_the_bench_size(raft_sd):
+    """`ofgen.RAFT_2`'s network (context-encoder BatchNorm on each image's own statistics, cnet_norm='batch') on the bench clip
+    through the bench's own step: 8 frames of 512x768 against the shared key frame, frames {0, 7} against the CPU oracle in the same
+    mode -- and at least 0.1 px away from the eval-mode network, so the two cannot be mixed up."""
+    import bench
+    from sd_animation_optical_flow_amd.raft import RaftEngine
+    B, H, W = 8, bench.H, bench.W
+    frames, key, key_ai, conf = bench.make_clip(B, H, W, torch.device("cuda"))
+    engb = RaftEngine(raft_sd, cnet_norm="batch")
+    flow, warped, mask = bench.make_step(engb, frames, key, key_ai, conf)()
+    kf = key.cpu().permute(2, 0, 1)[None].float()
+    for b in (0, 7):
+        a = frames[b].cpu().permute(2, 0, 1)[None].float()
+        _, up = RO.raft_forward(raft_sd, a, kf, iters=bench.ITERS, cnet_norm="batch")
+        e = _epe(flow[b].cpu(), up[0].permute(1, 2, 0))
+        assert e < 1e-3, (b, e)
+    _, up_eval = RO.raft_forward(raft_sd, frames[0].cpu().permute(2, 0, 1)[None].float(), kf, iters=bench.ITERS)
+    assert _epe(flow[0].cpu(), up_eval[0].permute(1, 2, 0)) > 0.1
 
 
 def test_large_batch_on_a_map_that_is_not_whole_patches(engine, raft_sd):
@@ -346,7 +371,7 @@ def test_headline_size_parity_against_a_float64_yardstick(engine, raft_sd):
     sd64 = RO.to_float64(raft_sd)
     kf = key.cpu().permute(2, 0, 1)[None].float()
     flow = engine.forward(frames, key, iters=bench.ITERS)
-    for b in (0, 31, 63):
+    for b in (31,):        # one pair here (the float64 oracle costs ~20 s of CPU per pair); bench.py's `verified` block reports three
         a = frames[b].cpu().permute(2, 0, 1)[None].float()
         _, up32 = RO.raft_forward(raft_sd, a, kf, iters=bench.ITERS)
         _, up64 = RO.raft_forward(sd64, a.double(), kf.double(), iters=bench.ITERS)

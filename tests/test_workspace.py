@@ -82,3 +82,49 @@ def test_index_set_operations_and_adjacent_frames():
     # ties keep the first run
     assert VideoFrameIndices([0, 10, 20, 30]).adjacent_frames(15, 2).indices == [10, 20]
     assert VideoFrameIndices([0, 10, 20, 30]).adjacent_frames(10, 1).indices == [10]
+
+
+# ------------------------------------------------------------------------------------------------
+# hostio: the asynchronous host side of the workspace driver (CPU device: threads, staging ring, error propagation)
+# ------------------------------------------------------------------------------------------------
+def _small_workspace(tmp_path, n=11, H=12, W=20, seed=7):
+    rng = np.random.default_rng(seed)
+    frames = [rng.integers(0, 256, (H, W, 3), dtype=np.uint8) for _ in range(n)]
+    return VideoData(frames, (W, H), str(tmp_path / "ws")), frames
+
+
+def test_frame_loader_prefetches_batches_in_any_order(tmp_path):
+    import torch
+    from sd_animation_optical_flow_amd import hostio
+    video, frames = _small_workspace(tmp_path)
+    for threads in (0, 3):
+        loader = hostio.FrameLoader(video, "cpu", threads=threads, slots=2, batch=4)
+        tickets = [loader.request(ids) for ids in ([0, 1, 2, 3], [4], [10, 9, 8], [5, 6, 7, 2])]     # more requests than ring slots
+        for t, ids in zip(tickets, ([0, 1, 2, 3], [4], [10, 9, 8], [5, 6, 7, 2])):
+            got = loader.fetch(t)
+            assert got.dtype == torch.uint8 and tuple(got.shape) == (len(ids), 12, 20, 3)
+            assert np.array_equal(got.numpy(), np.stack([frames[i] for i in ids]))
+        if threads:
+            with pytest.raises(ValueError):
+                loader.request([0, 1, 2, 3, 4])                 # over the batch the staging buffers were sized for
+            bad = loader.request([3, 99])                       # a frame that does not exist: the failure surfaces at fetch
+            with pytest.raises(Exception):
+                loader.fetch(bad)
+        loader.close()
+
+
+def test_frame_writer_writes_every_frame_and_reports_failures(tmp_path):
+    import torch
+    from sd_animation_optical_flow_amd import hostio
+    video, frames = _small_workspace(tmp_path)
+    for threads in (0, 3):
+        w = hostio.FrameWriter(video, "cpu", threads=threads, slots=2)             # fewer staging slots than frames: put() must recycle
+        for i, f in enumerate(frames):
+            w.put(i, torch.from_numpy(255 - f))
+        w.close()
+        assert all(np.array_equal(video.get_ai_frame(i), 255 - f) for i, f in enumerate(frames))
+    w = hostio.FrameWriter(video, "cpu", threads=2)
+    w.put(0, torch.from_numpy(frames[0]))
+    w.put(1, torch.zeros((12, 20), dtype=torch.uint8))          # not a [H,W,3] frame: the encoder thread raises ...
+    with pytest.raises(ValueError):
+        w.close()                                               # ... and flush / close re-raises it
