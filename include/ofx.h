@@ -261,16 +261,6 @@ int ofx_corr_volume(const float* f1, const float* f2, float* const* pyr, int B, 
  * out row stride ldo */
 int ofx_corr_lookup(const float* const* pyr, const float* coords, float* out, int ldo, int B, int h,
                     int w, int levels, int radius, void* stream);
-/* CorrBlock.__call__ (4 levels, radius 4: RAFT/core/corr.py:29-50) fused into relu(convc1(.)) of the motion encoder
- * (RAFT/core/update.py:79-86): out[m, 0:256] = relu(W * lookup(m) + bias); the 324-float correlation row never reaches HBM.
- * pyr: the blocked pyramid of ofx_corr_volume (4 levels); coords [B*h*w][2]; out row stride ldo >= 256; bias_dev [256].
- * wf_dev: convc1's weight in the order the kernel streams it -- pack once on the host with ofx_corr_lookup_convc1_pack
- * (w_host: [256][324] = OIHW of the 1x1 kernel, channel k = l*81 + i*9 + j as the lookup orders them; out_host:
- * ofx_corr_lookup_convc1_pack_floats() floats) and upload (16-byte aligned). */
-long ofx_corr_lookup_convc1_pack_floats(void);
-int ofx_corr_lookup_convc1_pack(const float* w_host, float* out_host);
-int ofx_corr_lookup_convc1(const float* const* pyr, const float* coords, const float* wf_dev, const float* bias_dev,
-                           float* out, int ldo, int B, int h, int w, void* stream);
 /* alt_cuda_corr.forward: fmap1 [B,H1,W1,C], fmap2 [B,H2,W2,C], coords [B,N,H1,W1,2] ->
  * corr [B,N,(2r+1)^2,H1,W1] (overwritten, not accumulated into).  C % 4 == 0. */
 int ofx_local_corr_fwd(const float* fmap1, const float* fmap2, const float* coords, float* corr,
@@ -322,8 +312,6 @@ size_t ofx_raft_workspace_bytes(const ofx_raft* r, int B, int H, int W);
                                      a model never put in .eval(), one image per call) instead of the folded running statistics */
 #define OFX_RAFT_SEPARATE_STATS 256 /* diagnostic: instance-norm statistics by their own f64 pass over the stored tensor instead of
                                      out of the convolution epilogues (fp32 partial sums per wave) */
-#define OFX_RAFT_FUSED_LOOKUP 512   /* opt-in: the correlation lookup and convc1 as ONE kernel (ofx_corr_lookup_convc1; the `corr` stage
-                                     buffer is then not produced).  Same results; measured slower than the two kernels so far. */
 #define OFX_RAFT_SERIAL       32  /* keep every launch on the caller's stream (default: small batches run their
                                      independent chains on internal side streams, joined before returning) */
 

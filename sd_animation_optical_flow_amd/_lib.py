@@ -91,9 +91,6 @@ SIGNATURES = {
     "ofx_corr_slice_floats": (_i, [_i, _i]),
     "ofx_corr_volume": (_i, [_p, _p, C.POINTER(_p), _i, _i, _i, _i, _i, _p]),
     "ofx_corr_lookup": (_i, [C.POINTER(_p), _p, _p, _i, _i, _i, _i, _i, _i, _p]),
-    "ofx_corr_lookup_convc1_pack_floats": (_l, []),
-    "ofx_corr_lookup_convc1_pack": (_i, [_p, _p]),
-    "ofx_corr_lookup_convc1": (_i, [C.POINTER(_p), _p, _p, _p, _p, _i, _i, _i, _i, _p]),
     "ofx_local_corr_fwd": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
     "ofx_local_corr_bwd": (_i, [_p] * 6 + [_i] * 8 + [_p]),
     "ofx_avgpool2_nhwc": (_i, [_p, _p, _i, _i, _i, _i, _p]),

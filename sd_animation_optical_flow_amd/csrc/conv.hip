@@ -279,7 +279,13 @@ __global__ __launch_bounds__(256 * KS, (BK == 16 && KS == 1) ? (PREC == 3 ? 2 : 
         // the (row, float4 slot) pairs this thread stages per slab; rows permuted like r0 (conflict-free ds_write_b128)
         constexpr int NSLOT = (kPatchRows * QPR + 255) / 256;
         constexpr int SROWS = 256 / QPR;                     // rows between a thread's consecutive slots
-        int avo0[NSLOT], avo1[NSLOT];
+        // The 256-row tile keeps one pixel index per slot and forms the byte offset (pixel * row bytes of the slab's segment + the
+        // thread's float4 slot) when a slab is issued -- a multiply per slot and slab instead of two resident offset tables: its six
+        // slots x two segments were registers it spilled at four workgroups per CU (28 -> 12-20 bytes of scratch).  The 128-row tiles
+        // keep both tables: they fit, and forming offsets late cost the GRU z|r kernel a spill of its own.
+        constexpr bool LAZY_OFF = BM == 256;
+        int apixs[LAZY_OFF ? NSLOT : 1];
+        int avo0[LAZY_OFF ? 1 : NSLOT], avo1[LAZY_OFF ? 1 : NSLOT];
         int alds0 = 0;                                       // slot q sits q * SROWS rows below slot 0 (the row permutation keeps j / 16)
         unsigned aval = 0;
 #pragma unroll
@@ -291,8 +297,12 @@ __global__ __launch_bounds__(256 * KS, (BK == 16 && KS == 1) ? (PREC == 3 ? 2 : 
             const int gy = pt_y0 - p.padH + hy, gx = pt_x0 - p.padW + hx;
             const bool ok = j < kPatchRows && row < (kPH + p.KH - 1) * PWH && (unsigned)gy < (unsigned)p.Hin && (unsigned)gx < (unsigned)p.Win;
             const int pix = (pt_b * p.Hin + gy) * p.Win + gx;
-            avo0[q] = ok ? pix * (p.ld0 * 4) + kq * 16 : kOOB;
-            avo1[q] = ok ? pix * (p.ld1 * 4) + kq * 16 : kOOB;
+            if constexpr (LAZY_OFF) {
+                apixs[q] = ok ? pix : 0;
+            } else {
+                avo0[q] = ok ? pix * (p.ld0 * 4) + kq * 16 : kOOB;
+                avo1[q] = ok ? pix * (p.ld1 * 4) + kq * 16 : kOOB;
+            }
             if (q == 0) alds0 = PREC == 0 ? row * LDK + kq * 4 : row * ROWB + kq * 8;   // floats / bytes
             aval |= (ok ? 1u : 0u) << q;
         }
@@ -339,9 +349,13 @@ __global__ __launch_bounds__(256 * KS, (BK == 16 && KS == 1) ? (PREC == 3 ? 2 : 
             const bool s0 = c < p.c0;                        // wave-uniform
             const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(s0 ? in0 : in1s), (short)0, s0 ? p.bytes0 : bytes1s, 0x00020000);
             const int so = (s0 ? c : c - p.c0) * 4;
+            const int ldb = (s0 ? p.ld0 : p.ld1) * 4;        // scalar
 #pragma unroll
             for (int q = 0; q < NSLOT; ++q) {
-                v4i t = __builtin_amdgcn_raw_buffer_load_b128(rs, s0 ? avo0[q] : avo1[q], so, 0);
+                int vo;
+                if constexpr (LAZY_OFF) vo = ((aval >> q) & 1u) ? apixs[q] * ldb + kq * 16 : kOOB;
+                else vo = s0 ? avo0[q] : avo1[q];
+                v4i t = __builtin_amdgcn_raw_buffer_load_b128(rs, vo, so, 0);
                 pa[q] = *reinterpret_cast<float4*>(&t);
             }
             if (NORM) {
@@ -1418,6 +1432,9 @@ extern "C" int ofx_conv2d_alpha(const ofx_conv_desc* d, float alpha, void* strea
             tl_stats.rows_per_image = (int)rows;
         }
     }
+#ifdef OFX_CONV_LEAN   // experiment builds (tools/build_variant.sh): fp32 only -- a third of the instantiations, a third of the compile time
+    if (d->precision != OFX_PREC_FP32) return OFX_EINVAL;
+#else
     if (d->precision != OFX_PREC_FP32) {
         // split-bf16 matrix-core path (opt-in): three tiles; every other choice is mapped onto them (the ragged
         // N of a 96- or 2-channel layer is zero-filled by the descriptors)
@@ -1446,10 +1463,13 @@ extern "C" int ofx_conv2d_alpha(const ofx_conv_desc* d, float alpha, void* strea
         if (bm == 64 && bn == 64) return wsplit ? launch_tile<64, 64, 32, 32, 16, 2>(k, d->epi, norm, nz, s) : launch_tile<64, 64, 32, 32, 16, 1>(k, d->epi, norm, nz, s);
         return OFX_EINVAL;
     }
+#endif
     if (tl_pool.on) {
         k.mtiles = (int)((M + 127) / 128);
         k.ntiles = (d->Cout + 127) / 128;
         k.group_m = k.ntiles >= 8 ? 8 : 1;
+        static const char* gm_env = getenv("OFX_VOL_GROUP_M");      // raster probe: M-tiles per group of the wide-N volume GEMM
+        if (gm_env && atoi(gm_env) > 0) k.group_m = atoi(gm_env);
         k.ksplit = 1;
         return launch_tile<128, 128, 64, 64, 16>(k, kEpiVolPool, false, nz, s);
     }

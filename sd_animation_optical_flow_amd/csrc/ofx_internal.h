@@ -66,13 +66,6 @@ int ofx_corr_block_rows(const float* src, float* dst, int n, int h, int w, int D
 int ofx_corr_pool_launch(const float* l0, float* l1, float* l2, float* l3, int B, int h, int w, int levels, hipStream_t s,
                          bool from_l1 = false);
 bool ofx_corr_volpool_ok(int h, int w);
-// lookup_conv.hip: CorrBlock.__call__ fused into relu(convc1(.)) -- the 324-float row per pixel never reaches HBM.
-// `wf`: convc1's weights in MFMA fragment order (ofx_lookup_conv_pack, ofx_lookup_conv_pack_floats() floats), device, 16-byte aligned
-long ofx_lookup_conv_pack_floats();
-int ofx_lookup_conv_pack(const float* w, int ldw, float* out);
-bool ofx_lookup_conv_ok(int h, int w);
-int ofx_lookup_conv_launch(const float* const* pyr, const float* coords, const float* wf, const float* bias, float* out, int ldo, int B,
-                           int h, int w, hipStream_t s);
 // mask_bits.hip: binary threshold/edge source -> elliptical dilation on bit planes
 enum { OFX_MSRC_CONF_LT = 0, OFX_MSRC_CONF_NGT = 1, OFX_MSRC_EDGES = 3 };   // conf < t | !(conf > t) | Laplacian edges
 int ofx_mask_bits_launch(int src, const float* conf, float* log_conf, const uint8_t* image, const uint8_t* or_mask,

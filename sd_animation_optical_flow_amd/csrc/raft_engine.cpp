@@ -101,7 +101,6 @@ struct ofx_raft {
     // gamma / beta of the context encoder's BatchNorm layers for the batch-statistics mode (OFX_RAFT_BN_BATCH), by norm name
     std::map<std::string, std::pair<float*, float*>> affine;
     std::vector<void*> allocs;
-    float* convc1_frag = nullptr;      // convc1's weights in the fragment order of the fused lookup + convolution kernel (lookup_conv.hip)
     std::map<std::string, std::pair<void*, size_t>> bufs;
     // side streams for the small-batch schedule (see overlap_pays): independent chains of a forward run
     // concurrently and are joined back into the caller's stream with events
@@ -565,7 +564,7 @@ static RaftWs carve(void* base, size_t cap, int B, int H, int W, int flags, int 
 // everything after the feature / context encoders and the correlation volume: state init, the loop-invariant
 // GRU terms, `iters` refinement iterations, mask head, convex upsample
 static int run_recurrence(ofx_raft* r, const RaftWs& ws, int B, int h, int w, int iters, bool alt, bool shared,
-                          float* flow_up, float* flow_low, hipStream_t s, int precision, bool overlap, bool want_fused_lookup,
+                          float* flow_up, float* flow_low, hipStream_t s, int precision, bool overlap,
                           uint8_t* warped = nullptr, float warp_sign = 1.0f, int n_warp = -1) {
     const long N = (long)h * w;
     const bool sh1 = shared, sh2 = shared;
@@ -594,12 +593,6 @@ static int run_recurrence(ofx_raft* r, const RaftWs& ws, int B, int h, int w, in
     auto C = [&](const char* k) -> const ConvW& { return r->convs[k]; };
     const float* pyr_c[LEVELS] = {ws.pyr[0], ws.pyr[1], ws.pyr[2], ws.pyr[3]};
     const int rd2 = (2 * RADIUS + 1) * (2 * RADIUS + 1);
-    // lookup + convc1 as ONE kernel (lookup_conv.hip: the 324-float correlation row per pixel stays in LDS) -- opt-in through
-    // OFX_RAFT_FUSED_LOOKUP / OFX_FUSED_LOOKUP=1: parity-green but measured slower than the two kernels it replaces (see the header of
-    // lookup_conv.hip).  fp32 arithmetic, the volume path, the reference's 4 levels x radius 4 only.
-    static const bool env_fused = getenv("OFX_FUSED_LOOKUP") != nullptr;
-    const bool fused_lookup = !alt && (want_fused_lookup || env_fused) && precision == OFX_PREC_FP32 && r->convc1_frag != nullptr &&
-                              ofx_lookup_conv_ok(h, w);
     for (int it = 0; it < iters && !L.st; ++it) {
         // flow features (update.py:93-94) on the side stream, from the flow the previous iteration left
         if ((L.st = S.fork(0))) break;
@@ -607,11 +600,7 @@ static int run_recurrence(ofx_raft* r, const RaftWs& ws, int B, int h, int w, in
         LF.conv(C("convf2"), ws.f1, 128, 128, nullptr, 0, 0, ws.corflo + 192, 256, B, h, w, 1, OFX_ACT_RELU);
         if ((L.st = LF.st)) break;
         // correlation features at the current estimate
-        if (fused_lookup) {
-            ofx_prof_set_tag("convc1");
-            L.st = ofx_lookup_conv_launch(pyr_c, ws.coords1, r->convc1_frag, C("convc1").shift, ws.c1, 256, B, h, w, s);
-            ofx_prof_set_tag(nullptr);
-        } else if (!alt) {
+        if (!alt) {
             L.st = ofx_corr_lookup(pyr_c, ws.coords1, ws.corr, CORR_CH, B, h, w, LEVELS, RADIUS, s);
         } else {
             for (int l = 0; l < LEVELS && !L.st; ++l) {
@@ -622,7 +611,7 @@ static int run_recurrence(ofx_raft* r, const RaftWs& ws, int B, int h, int w, in
             }
         }
         // motion encoder (update.py:88-97)
-        if (!fused_lookup) L.conv(C("convc1"), ws.corr, CORR_CH, CORR_CH, nullptr, 0, 0, ws.c1, 256, B, h, w, 1, OFX_ACT_RELU);
+        L.conv(C("convc1"), ws.corr, CORR_CH, CORR_CH, nullptr, 0, 0, ws.c1, 256, B, h, w, 1, OFX_ACT_RELU);
         L.conv(C("convc2"), ws.c1, 256, 256, nullptr, 0, 0, ws.corflo, 256, B, h, w, 1, OFX_ACT_RELU);
         if (!L.st) L.st = S.join(0);
         L.conv(C("conv"), ws.corflo, 256, 256, nullptr, 0, 0, ws.hx + MOT_OFF, HX_LD, B, h, w, 1, OFX_ACT_RELU);
@@ -696,14 +685,6 @@ int ofx_raft_create(const ofx_tensor* tensors, int n, ofx_raft** out) {
     if (!st) st = build_encoder(r, sd, "cnet", true, "cnetb");
     const char* ub = "update_block.";
     if (!st) st = add_conv(r, sd, std::string(ub) + "encoder.convc1", "convc1", 0, "", 1.f);
-    if (!st) {   // the same weights once more, in the fragment order of the fused lookup + convc1 kernel
-        const HostTensor* wc = find(sd, std::string(ub) + "encoder.convc1.weight");
-        if (wc && wc->ndim == 4 && wc->shape[0] == 256 && wc->shape[1] == CORR_CH && wc->shape[2] == 1 && wc->shape[3] == 1) {
-            std::vector<float> frag((size_t)ofx_lookup_conv_pack_floats());
-            st = ofx_lookup_conv_pack(wc->data, CORR_CH, frag.data());
-            if (!st) st = upload(r, frag, &r->convc1_frag);
-        }
-    }
     if (!st) st = add_conv(r, sd, std::string(ub) + "encoder.convc2", "convc2", 0, "", 1.f);
     std::vector<float> wf1;   // must outlive add_conv below
     if (!st) {
@@ -887,7 +868,7 @@ static int raft_forward_impl(ofx_raft* r, const uint8_t* image1, const uint8_t* 
         st = ofx_warp_pad_launch(warp_frame, ws.warp_pad, H, W, s);
         if (st) return st;
     }
-    st = run_recurrence(r, ws, B, h, w, iters, alt, sh1 || sh2, flow_up, flow_low, s, prec, overlap, flags & OFX_RAFT_FUSED_LOOKUP, warped,
+    st = run_recurrence(r, ws, B, h, w, iters, alt, sh1 || sh2, flow_up, flow_low, s, prec, overlap, warped,
                         warp_sign);
     if (st) return st;
 
@@ -999,7 +980,7 @@ int ofx_raft_forward_pairs_warp(ofx_raft* r, const uint8_t* images, int n_images
         st = ofx_warp_pad_launch(warp_frame, ws.warp_pad, H, W, s);
         if (st) return st;
     }
-    st = run_recurrence(r, ws, B, h, w, iters, false, false, flow_up, flow_low, s, prec, overlap, flags & OFX_RAFT_FUSED_LOOKUP, warped, warp_sign,
+    st = run_recurrence(r, ws, B, h, w, iters, false, false, flow_up, flow_low, s, prec, overlap, warped, warp_sign,
                         n_warp);
     if (st) return st;
     r->bufs.clear();

@@ -371,38 +371,6 @@ def corr_lookup(pyr: Sequence[torch.Tensor], coords: torch.Tensor, B: int, h: in
     return out
 
 
-def pack_lookup_conv_weight(weight: torch.Tensor, device="cuda") -> torch.Tensor:
-    """convc1's weight [256,324] / [256,324,1,1] -> the fragment order `corr_lookup_convc1` streams, on the device (pack once)."""
-    wt = weight.detach().to(torch.float32).reshape(weight.shape[0], -1).contiguous().cpu()
-    if tuple(wt.shape) != (256, 324):
-        raise RuntimeError(f"weight must be [256,324], got {tuple(wt.shape)}")
-    L = _lib.lib()
-    out = torch.empty((L.ofx_corr_lookup_convc1_pack_floats(),), dtype=torch.float32)
-    check(L.ofx_corr_lookup_convc1_pack(C.c_void_p(wt.data_ptr()), C.c_void_p(out.data_ptr())), "ofx_corr_lookup_convc1_pack")
-    return out.to(device)
-
-
-def corr_lookup_convc1(pyr: Sequence[torch.Tensor], coords: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, B: int, h: int,
-                       w: int) -> torch.Tensor:
-    """relu(convc1(CorrBlock.__call__(coords))) in ONE kernel (RAFT/core/corr.py:29-50 + update.py:79-86): the 324-float
-    correlation row of a pixel is produced into LDS and consumed by the 1x1 convolution there.  pyr: the 4-level blocked
-    pyramid; coords f32 [B,h,w,2]; weight: [256,324(,1,1)] (packed on the fly) or the result of `pack_lookup_conv_weight`;
-    bias [256].  Returns f32 [B,h,w,256]."""
-    c = _chk(coords, "coords", torch.float32)
-    if len(pyr) != 4:
-        raise RuntimeError("corr_lookup_convc1 serves the reference configuration: 4 pyramid levels, radius 4")
-    for i, p in enumerate(pyr):
-        _chk(p, f"pyr[{i}]", torch.float32)
-    packed = weight if (weight.dim() == 1 and weight.is_cuda) else pack_lookup_conv_weight(weight, c.device)
-    _chk(packed, "packed weight", torch.float32)
-    bs = _chk(bias.detach().to(torch.float32).contiguous().to(c.device), "bias", torch.float32)
-    out = torch.empty((B, h, w, 256), dtype=torch.float32, device=c.device)
-    arr = (C.c_void_p * 4)(*[p.data_ptr() for p in pyr])
-    check(_lib.lib().ofx_corr_lookup_convc1(arr, _ptr(c), _ptr(packed), _ptr(bs), _ptr(out), 256, B, h, w, _stream()),
-          "ofx_corr_lookup_convc1")
-    return out
-
-
 def local_corr(fmap1: torch.Tensor, fmap2: torch.Tensor, coords: torch.Tensor, radius: int) -> torch.Tensor:
     """`alt_cuda_corr.forward` semantics; see alt_cuda_corr.py."""
     a = _chk(fmap1, "fmap1", torch.float32)

@@ -16,7 +16,7 @@ import torch.nn.functional as F
 from . import _lib
 from ._lib import check
 
-FLAG_BGR, FLAG_SHARED_IMG2, FLAG_SHARED_IMG1, FLAG_ALT_CORR, FLAG_BF16X3, FLAG_SERIAL, FLAG_BF16X6, FLAG_BN_BATCH, FLAG_SEPARATE_STATS, FLAG_FUSED_LOOKUP = 1, 2, 4, 8, 16, 32, 64, 128, 256, 512
+FLAG_BGR, FLAG_SHARED_IMG2, FLAG_SHARED_IMG1, FLAG_ALT_CORR, FLAG_BF16X3, FLAG_SERIAL, FLAG_BF16X6, FLAG_BN_BATCH, FLAG_SEPARATE_STATS = 1, 2, 4, 8, 16, 32, 64, 128, 256
 CNET_NORMS = {"eval": 0, "batch": FLAG_BN_BATCH}
 PRECISIONS = {"fp32": 0, "bf16x3": FLAG_BF16X3, "bf16x6": FLAG_BF16X6}
 
@@ -113,14 +113,13 @@ class RaftEngine:
     @torch.no_grad()
     def forward(self, image1: torch.Tensor, image2: torch.Tensor, iters: int = 20, bgr: bool = False,
                 alternate_corr: bool = False, want_low: bool = False, serial: bool = False, separate_stats: bool = False,
-                fused_lookup: bool = False, warp_frame: Optional[torch.Tensor] = None, warp_sign: float = 1.0,
+                warp_frame: Optional[torch.Tensor] = None, warp_sign: float = 1.0,
                 want_flow: bool = True):
         """image1: uint8 [B,H,W,3] or [H,W,3] (shared by the batch); image2 likewise.  Flow is defined
         on image1's grid and points into image2.  Returns flow_up f32[B,H,W,2] (and flow_low).
         serial=True keeps every launch on the current stream (small batches otherwise overlap their
         independent chains on the engine's side streams; results are identical).  separate_stats=True (diagnostic) takes the
-        instance-norm statistics with their own f64 pass instead of out of the convolution epilogues.  fused_lookup=True (opt-in) runs
-        the correlation lookup and convc1 as one kernel (the `corr` stage buffer is then not produced).
+        instance-norm statistics with their own f64 pass instead of out of the convolution epilogues.
         warp_frame: uint8 [H,W,3] (one frame shared by the batch -- the rendered AI key frame): its bilinear backward warp along the
         final flow is produced INSIDE the convex upsample (`ofx_raft_forward_warp`; warp_sign +1 = pdcnet_of.warp_frame's convention,
         -1 = ofgen.warp_frame's) and returned after the flow: (flow_up[, flow_low], warped u8 [B,H,W,3]) -- bit-identical to
@@ -131,7 +130,7 @@ class RaftEngine:
                 raise RuntimeError(f"{nm} must be a CUDA tensor")
             if t.dtype != torch.uint8:
                 raise RuntimeError(f"{nm} must be uint8")
-        flags = (FLAG_BGR if bgr else 0) | PRECISIONS[self.precision] | (FLAG_SERIAL if serial else 0) | CNET_NORMS[self.cnet_norm] | (FLAG_SEPARATE_STATS if separate_stats else 0) | (FLAG_FUSED_LOOKUP if fused_lookup else 0)
+        flags = (FLAG_BGR if bgr else 0) | PRECISIONS[self.precision] | (FLAG_SERIAL if serial else 0) | CNET_NORMS[self.cnet_norm] | (FLAG_SEPARATE_STATS if separate_stats else 0)
         sh1, sh2 = image1.dim() == 3, image2.dim() == 3
         if sh1 and sh2:
             image1, sh1 = image1[None], False
@@ -165,7 +164,7 @@ class RaftEngine:
                 a = image1 if sh1 else image1[b0:b0 + max_pairs]
                 c = image2 if sh2 else image2[b0:b0 + max_pairs]
                 r = self.forward(a, c, iters=iters, bgr=bgr, alternate_corr=alternate_corr, want_low=want_low, serial=serial, separate_stats=separate_stats,
-                                 fused_lookup=fused_lookup, warp_frame=warp_frame, warp_sign=warp_sign, want_flow=want_flow)
+                                 warp_frame=warp_frame, warp_sign=warp_sign, want_flow=want_flow)
                 outs.append(r if isinstance(r, tuple) else (r,))
             cat = tuple(None if parts[0] is None else torch.cat(parts) for parts in zip(*outs))
             return cat if len(cat) > 1 else cat[0]

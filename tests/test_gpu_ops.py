@@ -427,41 +427,6 @@ def test_upsample_flow_with_the_warp_inside_is_the_two_kernels_bit_for_bit(cuda,
     assert (nchw(flow) - ref).abs().max().item() < 2e-3 * max(1.0, ref.abs().max().item())
 
 
-@pytest.mark.parametrize("shape", [(2, 16, 24), (1, 12, 8), (3, 17, 9), (1, 96, 64)])
-def test_corr_lookup_fused_into_convc1(cuda, shape):
-    """`ofx_corr_lookup_convc1`: CorrBlock.__call__ (corr.py:29-50) + relu(convc1(.)) (update.py:79-86) in one kernel, against
-    the oracle's two steps -- integer, fractional and far out-of-range coordinates; pixel counts that are not multiples of the
-    kernel's 64-pixel tile; NaN / huge coordinates must give finite output (zero window) like the lookup kernel."""
-    ops = _ops()
-    B, h, w = shape
-    g = torch.Generator().manual_seed(23)
-    f1 = torch.randn((B, 256, h, w), generator=g)
-    f2 = torch.randn((B, 256, h, w), generator=g)
-    ref_pyr = RO.corr_pyramid(f1, f2)
-    pyr = ops.corr_volume(nhwc(f1), nhwc(f2))
-    wt = (torch.rand((256, 324, 1, 1), generator=g) * 2 - 1) / 18.0
-    bias = (torch.rand((256,), generator=g) * 2 - 1) / 18.0
-    coords = RO.coords_grid(B, h, w)
-    for amp in (0.0, 3.3, 40.0):
-        c = coords + (torch.rand((B, 2, h, w), generator=g) - 0.5) * 2 * amp
-        ref = torch.relu(torch.nn.functional.conv2d(RO.corr_lookup(ref_pyr, c), wt, bias))
-        out = ops.corr_lookup_convc1(pyr, nhwc(c), wt, bias, B, h, w)
-        assert tuple(out.shape) == (B, h, w, 256)
-        err = (nchw(out) - ref).abs().max().item()
-        assert err < 2e-4 * max(1.0, ref.abs().max().item()), (amp, err)
-        # and against the two HIP kernels it replaces
-        two = torch.relu(torch.nn.functional.conv2d(nchw(ops.corr_lookup(pyr, nhwc(c), B, h, w)), wt, bias))
-        assert (nchw(out) - two).abs().max().item() < 1e-4 * max(1.0, ref.abs().max().item())
-    wild = nhwc(coords).clone()
-    wild[0, 0, 0, 0] = 3.0e9
-    wild[0, 1, 1, 1] = -3.0e9
-    out = ops.corr_lookup_convc1(pyr, wild.cuda(), wt, bias, B, h, w)
-    assert bool(torch.isfinite(out).all())
-    assert (out[0, 0, 0].cpu() - torch.relu(bias)).abs().max().item() < 1e-6     # an empty window leaves the bias
-    with pytest.raises(RuntimeError):
-        ops.corr_lookup_convc1(pyr[:3], nhwc(coords), wt, bias, B, h, w)
-
-
 def test_local_corr_backward_matches_oracle(cuda):
     """alt_cuda_corr.backward: gradients w.r.t. both feature maps against the oracle's restatement (itself equal to
     autograd of the pinned forward); C below, equal to and above one lane-quad sweep (64, 256, 320)."""

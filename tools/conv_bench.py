@@ -38,6 +38,15 @@ if os.environ.get("CONV_BENCH_B1"):
     ]
 
 
+if os.environ.get("CONV_BENCH_C1"):      # the motion encoder's 1x1 over the correlation channels, as laid out today and padded to whole chunks
+    SHAPES = [
+        ("warm-up 3x3 256->192", 64, 96, 64, 256, 192, 3, 3, 1, 0),
+        ("1x1 324->256", 64, 96, 64, 324, 256, 1, 1, 1, 0),
+        ("1x1 336->256", 64, 96, 64, 336, 256, 1, 1, 1, 0),
+        ("1x1 352->256", 64, 96, 64, 352, 256, 1, 1, 1, 0),
+        ("1x1 256->576", 64, 96, 64, 256, 576, 1, 1, 1, 0),
+    ]
+    TILES = [0, 16128064, 32128128, 32128064]
 if os.environ.get('CONV_BENCH_TILES'):
     TILES = [int(t) for t in os.environ['CONV_BENCH_TILES'].split(',')]
 if os.environ.get("CONV_BENCH_ONLY"):
@@ -72,7 +81,7 @@ def run(libpath):
                 assert lib.ofx_conv2d(C.byref(d), s) == 0
             torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            n = 10
+            n = int(os.environ.get('CONV_BENCH_REPS', '10'))
             e0.record()
             for _ in range(n):
                 lib.ofx_conv2d(C.byref(d), s)

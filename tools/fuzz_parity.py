@@ -26,20 +26,19 @@ for case in range(int(sys.argv[2]) if len(sys.argv) > 2 else 16):
     img2 = key if shared else key[None].repeat(B, 1, 1, 1) if random.random() < 0.5 else frames.flip(0).contiguous()
     ref2 = (img2[None].repeat(B, 1, 1, 1) if img2.dim() == 3 else img2).permute(0, 3, 1, 2).float()
     norm = random.choice(["eval", "batch"])
-    fused = (not alt) and random.random() < 0.5                          # the opt-in lookup + convc1 kernel
     warp = random.random() < 0.5 and H >= 128 and W >= 128               # the warp inside the upsample (u8 frame of the same size)
     _, up_ref = RO.raft_forward(sd, frames.permute(0, 3, 1, 2).float(), ref2, iters=iters, alternate_corr=alt, cnet_norm=norm)
     e = eng_b if norm == "batch" else eng
     if warp:
         ai = torch.randint(0, 256, (H, W, 3), generator=g, dtype=torch.uint8).cuda()
-        up, wp = e.forward(frames.cuda(), img2.cuda(), iters=iters, alternate_corr=alt, fused_lookup=fused, warp_frame=ai)
+        up, wp = e.forward(frames.cuda(), img2.cuda(), iters=iters, alternate_corr=alt, warp_frame=ai)
         from oracle import warp_oracle as WO
         d = np.abs(wp[0].cpu().numpy().astype(np.int32) - WO.warp_frame(ai.cpu().numpy(), up[0].cpu().numpy(), mode="bilinear").astype(np.int32))
         assert d.max() <= 1 and (d > 0).mean() < 2e-3, "warp inside the upsample"
     else:
-        up = e.forward(frames.cuda(), img2.cuda(), iters=iters, alternate_corr=alt, fused_lookup=fused)
+        up = e.forward(frames.cuda(), img2.cuda(), iters=iters, alternate_corr=alt)
     epe = (up.cpu() - up_ref.permute(0, 2, 3, 1)).pow(2).sum(-1).sqrt().mean().item()
     worst = max(worst, epe)
-    print(f"case {case:2d}: {W}x{H} B={B} iters={iters} shared={shared} alt={alt} norm={norm} fused={fused} warp={warp}: EPE {epe:.2e}", flush=True)
+    print(f"case {case:2d}: {W}x{H} B={B} iters={iters} shared={shared} alt={alt} norm={norm} warp={warp}: EPE {epe:.2e}", flush=True)
     assert epe < 1e-3, "parity bar exceeded"
 print(f"worst EPE {worst:.2e}")

@@ -22,22 +22,15 @@ ms = e0.elapsed_time(e1) / 20
 byts = B * h * w * (400 * 4 + 324 * 4 + 8)
 print(f"lookup B={B}: {ms * 1e3:7.1f} us  {byts / ms / 1e9:.2f} TB/s algorithmic ({byts / ms / 1e9 / 80:.1f} % of 8 TB/s)")
 
-# the lookup fused into convc1 (lookup_conv.hip) against the two kernels it replaces
+# lookup, then convc1 (the motion encoder's 1x1 over the 324 correlation channels, update.py:86)
 wt = (torch.rand((256, 324), device="cuda", generator=g) * 2 - 1) / 18
 bias = torch.zeros((256,), device="cuda")
-packed = ops.pack_lookup_conv_weight(wt)
 wc = ops.pack_conv_weight(wt.reshape(256, 324, 1, 1).cpu()).cuda()
-fused = lambda: ops.corr_lookup_convc1(pyr, coords, packed, bias, B, h, w)
 two = lambda: ops.conv2d_nhwc(ops.corr_lookup(pyr, coords, B, h, w), wc, 1, 1, 256, shift=bias, act="relu")
-for name, f in (("fused lookup+convc1", fused), ("lookup, then convc1", two)):
-    for _ in range(3): f()
-    torch.cuda.synchronize()
-    e0.record()
-    for _ in range(20): f()
-    e1.record(); torch.cuda.synchronize()
-    ms = e0.elapsed_time(e1) / 20
-    fl = 2.0 * B * h * w * 324 * 256
-    wb = B * h * w * (400 * 4 + 8)
-    print(f"{name}: {ms * 1e3:7.1f} us  {fl / ms / 1e9:.1f} TFLOP/s (324-k GEMM), windows + coords {wb / ms / 1e9:.2f} TB/s")
-a, b2 = fused(), two()
-print("max |fused - two kernels| =", (a - b2).abs().max().item())
+for _ in range(3): two()
+torch.cuda.synchronize()
+e0.record()
+for _ in range(20): two()
+e1.record(); torch.cuda.synchronize()
+ms = e0.elapsed_time(e1) / 20
+print(f"lookup, then convc1: {ms * 1e3:7.1f} us  {2.0 * B * h * w * 324 * 256 / ms / 1e9:.1f} TFLOP/s (324-k GEMM)")
