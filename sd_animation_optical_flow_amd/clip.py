@@ -154,7 +154,8 @@ class FrameSynthesizer:
             if fuse:
                 flow, warped = self.engine.forward(frames, key_raw, iters=self.iters, bgr=self.bgr, warp_frame=key_ai)
             else:
-                flow, warped = self.engine.forward(frames, key_raw, iters=self.iters, bgr=self.bgr), None
+                from .pdcnet_of import _unpad
+                flow, warped = _unpad(self.engine.forward(frames, key_raw, iters=self.iters, bgr=self.bgr), H, W), None   # (padded to /8 inside)
         elif self.algo is not None:
             if fuse:
                 flow, conf, _, warped = self.algo.calc_batch_device(key_raw, frames, bgr=self.bgr, warp_frame=key_ai)

@@ -383,19 +383,25 @@ struct EncBufs {
 // --------------------------------------------------------------------------------------------
 static int run_encoder(ofx_raft* r, const std::string& enc, bool bn, const uint8_t* imgs, int n, int H, int W,
                        int bgr, const EncBufs& eb, float* out, int out_ld, bool split_tanh_relu, int relu_off, hipStream_t s,
-                       int precision = OFX_PREC_FP32, bool separate_stats = false) {
+                       int precision = OFX_PREC_FP32, bool separate_stats = false, const uint8_t* extra = nullptr) {
+    // `extra`: one more image appended to the chunk (the shared key frame riding with the frames: see raft_forward_impl)
     // `out`: [n*h*w][out_ld]; fnet writes 256 channels; cnet writes tanh(0:128) | relu(128:256)
     Launcher L{s};
     L.precision = precision;
     L.sk_ws = eb.sk; L.sk_bytes = eb.sk_bytes;
     const int H2 = H / 2, W2 = W / 2, H4 = H / 4, W4 = W / 4, H8 = H / 8, W8 = W / 8;
-    const int SC = ENC_CHUNK * 128;   // floats per stats vector slot
+    const int SC = (ENC_CHUNK + 1) * 128;   // floats per stats vector slot
     float* m1 = eb.stats + 0 * SC; float* s1 = eb.stats + 1 * SC;
     float* m2 = eb.stats + 2 * SC; float* s2 = eb.stats + 3 * SC;
     float* m3 = eb.stats + 4 * SC; float* s3 = eb.stats + 5 * SC;
     auto C = [&](const std::string& k) -> const ConvW& { return r->convs[enc + "." + k]; };
     int st = ofx_preprocess_u8(imgs, eb.x0, (long)n * H * W, bgr, s);
     if (st) return st;
+    if (extra) {
+        st = ofx_preprocess_u8(extra, eb.x0 + (long)n * H * W * 4, (long)H * W, bgr, s);
+        if (st) return st;
+        ++n;
+    }
     // statistics of the tensor the conv() just before has written: from its epilogue's partial sums when it produced them.
     // `norm`: the layer's name -- for "cnetb" (BatchNorm on per-image statistics) its gamma / beta are folded into (mean, rstd)
     auto stats = [&](const float* x, long HW, int ch, float* mean, float* rstd, const std::string& norm) {
@@ -506,7 +512,7 @@ static RaftWs carve(void* base, size_t cap, int B, int H, int W, int flags, int 
     const long N = (long)h * wd;
     const long M = (long)B * N;
     const int most = n_images > 0 ? n_images : 2 * B;
-    const int nch = std::min(enc_chunk(H, W), most);
+    const int nch = std::min(enc_chunk(H, W) + 1, most);   // + 1: the shared key frame rides in the last chunk of the frames (fold_key)
     const long half = (long)(H / 2) * (W / 2) * 64;
     for (int e = 0; e < 3; ++e) w.sk[e] = overlap_pays(M) ? (void*)c.take(SK_BYTES / sizeof(float)) : nullptr;
     for (int e = 0; e < 3; ++e) {
@@ -523,8 +529,8 @@ static RaftWs carve(void* base, size_t cap, int B, int H, int W, int flags, int 
         eb.R1 = c.take((size_t)nch * half);
         eb.R2 = c.take((size_t)nch * half);
         eb.R3 = c.take((size_t)nch * (H / 4) * (W / 4) * 96);
-        eb.stats = c.take((size_t)6 * ENC_CHUNK * 128);
-        eb.scratch = c.take((size_t)ENC_CHUNK * 64 * 128 * 2 * 2);   // doubles: chunk x slices x C x {sum, sumsq}
+        eb.stats = c.take((size_t)6 * (ENC_CHUNK + 1) * 128);
+        eb.scratch = c.take((size_t)(ENC_CHUNK + 1) * 64 * 128 * 2 * 2);   // doubles: chunk x slices x C x {sum, sumsq}
         // one (sum, sumsq) pair per channel and 32 tile rows at most: the half-resolution 64-channel stage bounds it
         eb.spart_floats = (size_t)nch * (H / 2) * (W / 2) * 4 + 4096;
         eb.spart = c.take(eb.spart_floats);
@@ -806,12 +812,19 @@ static int raft_forward_impl(ofx_raft* r, const uint8_t* image1, const uint8_t* 
     const int ech = enc_chunk(H, W);
     if ((st = S.fork(0))) return st;
     if ((st = S.fork(1))) return st;
+    // A shared key frame encoded by itself is a single-image launch sequence on a 256-CU part (1.3 ms where 1/64 of the frames' pass is
+    // 0.3): large batches append it to the last chunk of the frames instead -- instance norm is per image, so the result is the same
+    // network; its feature map lands right behind the frames' (fmap2 follows fmap1 in the workspace).
+    const long half_bytes = (long)(H / 2) * (W / 2) * 64 * 4;
+    const bool fold_key = sh2 && !sh1 && !overlap_pays(M) && ws.fmap2 == ws.fmap1 + (long)n1 * N * FD &&   // (by batch size, not by schedule: OFX_RAFT_SERIAL must not change the arithmetic)
+                          (long)(std::min(ech, (n1 - 1) % ech + 1) + 1) * half_bytes < (1L << 31) - 4096;
     for (int i0 = 0; i0 < n1 && !st; i0 += ech) {
         const int n = std::min(ech, n1 - i0);
+        const bool last = i0 + n == n1;
         st = run_encoder(r, "fnet", false, image1 + i0 * img_bytes, n, H, W, bgr, ws.eb[0], ws.fmap1 + (long)i0 * N * FD, FD,
-                         false, 0, s, prec, sepst);
+                         false, 0, s, prec, sepst, (fold_key && last) ? image2 : nullptr);
     }
-    for (int i0 = 0; i0 < n2 && !st; i0 += ech) {
+    for (int i0 = 0; i0 < n2 && !st && !fold_key; i0 += ech) {
         const int n = std::min(ech, n2 - i0);
         st = run_encoder(r, "fnet", false, image2 + i0 * img_bytes, n, H, W, bgr, ws.eb[1], ws.fmap2 + (long)i0 * N * FD, FD,
                          false, 0, S.get(0), prec, sepst);

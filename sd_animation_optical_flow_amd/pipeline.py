@@ -50,7 +50,7 @@ class ClipPipeline:
 
     def __init__(self, algo, vae=None, render: Optional[Callable] = None, render_key: Optional[Callable] = None, batch: int = 64,
                  warp_mode: str = "bilinear", thres: float = 0.95, ksize: int = 7, mask_blur: float = 4.0, device=None,
-                 io_threads: int = 4, prefetch: int = 2):
+                 io_threads: int = 6, prefetch: int = 2):
         self.algo, self.vae = algo, vae
         self.render = render or _paste_raw
         self.render_key = render_key or (lambda raw: raw)
@@ -167,7 +167,8 @@ class ClipPipeline:
         the end (every file is on disk when `run` returns)."""
         from . import hostio
         flags = flags if flags is not None else self.shared_flags(video)
-        writer = hostio.FrameWriter(video, self.device, threads=self.io_threads)
+        # staging slots for three batches: `put` must never wait for an encoder while the next batch's kernels are still to be enqueued
+        writer = hostio.FrameWriter(video, self.device, threads=self.io_threads, slots=3 * self.batch)
         keys = []
         try:
             for pkt, raw, idx in self.packets(video, flags, writer=writer):

@@ -168,6 +168,12 @@ class _StubPipeline:
                     mask = ((raws[k][..., 0] > 128).to(torch.uint8) * 255)
                     out.append(pipeline.FramePacket(t, key_index, torch.zeros(1), torch.zeros(1), warped, mask, {}))
                 return out
+            def key_frame_flags(self, video, th=8.5):
+                # what each rank's OWN detector would say: only rank 0's answer is usable -- `shared_flags` must broadcast it
+                # (a rank acting on its own list here would plan other segments and the run would hang or write wrong frames)
+                from sd_animation_optical_flow_amd import clip
+                rank, _ = clip.dist_info()
+                return list(_FLAGS) if rank == 0 else [True] + [False] * (video.num_frames - 1)
         render = lambda pkt, raw: torch.where(pkt.mask[..., None] > 0, raw, pkt.warped)
         return P(algo=None, render=render, render_key=lambda raw: 255 - raw, batch=3, device=torch.device(device))
 
@@ -190,7 +196,7 @@ def _pipeline_worker(rank, world, port, ws):
     try:
         from sd_animation_optical_flow_amd.workspace import VideoData
         video = VideoData(None, (24, 16), ws)
-        keys = _StubPipeline.make().run(video, _FLAGS)
+        keys = _StubPipeline.make().run(video)          # flags=None: rank 0's key-frame decisions reach every rank by broadcast
         torch.save(keys, os.path.join(ws, f"keys_r{rank}.pt"))
         dist.barrier()
     finally:

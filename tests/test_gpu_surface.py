@@ -440,6 +440,29 @@ def test_clip_pipeline_end_to_end_over_a_workspace(algo, tmp_path):
     assert np.array_equal(out2[m], frames[2][m]) and np.array_equal(out2[~m], p.warped.cpu().numpy()[~m])
 
 
+def test_clip_pipeline_async_host_side_changes_no_byte(algo, tmp_path):
+    """`ClipPipeline.run` with the asynchronous host side (thread-pool PNG decode into pinned staging, H2D on a copy stream one batch
+    ahead, D2H + PNG encode off-thread: hostio.py) against the same run with everything inline (`io_threads=0`): every AI frame on disk
+    byte for byte the same, every frame written, key frames included."""
+    from sd_animation_optical_flow_amd import pipeline
+    from sd_animation_optical_flow_amd.workspace import VideoData
+    H, W = 64, 96
+    g = torch.Generator().manual_seed(321)
+    base = torch.nn.functional.avg_pool2d(torch.rand((1, 3, H + 80, W + 80), generator=g), 5, 1, 2)
+    base = ((base - base.min()) / (base.max() - base.min()) * 255).round().to(torch.uint8)[0].permute(1, 2, 0).numpy()
+    frames = [np.ascontiguousarray(base[20 + s:20 + s + H, 20 + 2 * s:20 + 2 * s + W]) for s in range(13)]
+    flags = [True] + [False] * 6 + [True] + [False] * 5
+    outs = []
+    for threads in (0, 3):
+        video = VideoData(frames, (W, H), str(tmp_path / f"ws{threads}"))
+        pipe = pipeline.ClipPipeline(algo, batch=4, warp_mode="bilinear", thres=0.9, ksize=7, io_threads=threads, prefetch=2)
+        assert pipe.run(video, flags) == [0, 7]
+        assert all(video.generated(i) for i in range(13))
+        outs.append([video.get_ai_frame(i) for i in range(13)])
+    for i in range(13):
+        assert np.array_equal(outs[0][i], outs[1][i]), i
+
+
 def test_config_c5_1024x1024_flow_warp_mask_against_the_oracle(cuda, raft_sd):
     """BASELINE config #5's frame size, the path's own half of it at full depth: one 1024x1024 pair, 20 iterations, flow
     against the CPU oracle (EPE bar 1e-3 px), then warp + mask of a small batch against their oracles and the hand-off +
