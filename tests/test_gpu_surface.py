@@ -212,6 +212,35 @@ def test_frame_synthesizer_and_process_clip_device_path(algo, raft_sd):
     assert (mask[0].cpu().numpy() != ref_mask).mean() < 2e-3                  # confidence agrees to ~1e-6: masks differ only at exact ties
 
 
+@pytest.mark.parametrize("H,W", [(96, 128), (100, 132)])
+def test_frame_synthesizer_bilinear_takes_the_warp_inside_the_upsample(algo, raft_sd, H, W):
+    """`FrameSynthesizer(warp_mode='bilinear')` -- what `ClipPipeline` and `bench.py` run -- in its three forms: through the algo
+    (flow both ways + forward-backward confidence, `ofx_raft_forward_pairs_warp`), through the engine with a confidence from the
+    caller (`ofx_raft_forward_warp`), and with the fusion switched off (upsample, then `ofx_warp_and_mask`): identical flow, warped
+    frame and mask, on a frame the network takes as is and on one it pads to a multiple of 8 (where the fused form steps aside)."""
+    from sd_animation_optical_flow_amd import clip, ops
+    a, _ = _pair(12, H, W)
+    key = torch.from_numpy(a[:, :, ::-1].copy()).cuda()
+    frames = torch.stack([torch.roll(key, shifts=(t - 1, 1 - 2 * t), dims=(0, 1)) for t in range(3)]).contiguous()
+    key_ai = (255 - key).contiguous()
+    fused = clip.FrameSynthesizer(algo, warp_mode="bilinear", thres=0.9, ksize=7)
+    plain = clip.FrameSynthesizer(algo, warp_mode="bilinear", thres=0.9, ksize=7, fuse_warp=False)
+    f1, c1, w1, m1 = fused.synthesize(frames, key, key_ai)
+    f2, c2, w2, m2 = plain.synthesize(frames, key, key_ai)
+    assert tuple(w1.shape) == (3, H, W, 3) and tuple(m1.shape) == (3, H, W) and tuple(f1.shape) == (3, H, W, 2)
+    assert torch.equal(f1, f2) and torch.equal(c1, c2) and torch.equal(w1, w2) and torch.equal(m1, m2)
+    assert torch.equal(w1, ops.warp(key_ai, f1.contiguous(), mode="bilinear", sign=1.0))
+    # engine + external confidence: one flow per pair, same frame -> key frame flow as the algo's forward half
+    conf = torch.rand((3, H, W), generator=torch.Generator().manual_seed(4)).cuda()
+    eng = clip.FrameSynthesizer(engine=algo.network, warp_mode="bilinear", thres=0.9, ksize=7)
+    f3, w3, m3 = eng(frames, key, key_ai, confidence=conf)
+    assert (f3 - f1).abs().max().item() < 1e-3                                   # (pairs call vs shared-key call: other tile schedules)
+    assert torch.equal(w3, ops.warp(key_ai, f3.contiguous(), mode="bilinear", sign=1.0))
+    assert torch.equal(m3, ops.generate_mask(conf, None, 0.9, 7))
+    with pytest.raises(ValueError):
+        eng(frames, key, key_ai)                                                 # an engine alone has no confidence to offer
+
+
 def test_large_frame_1024x1024_single_pair(cuda, raft_sd):
     """BASELINE config #5 frame size (flow part): 128x128 coarse grid, 1.43 GB pyramid, finite and self-consistent."""
     from sd_animation_optical_flow_amd.raft import RaftEngine
