@@ -111,7 +111,7 @@ constexpr int kKAlign = 32;   // packed weights are zero-padded along K to this 
 // same products in another summation order.  Why it matters: the rate of the general kernel follows the A bytes staged per MFMA
 // (DESIGN.md section 4), which this cuts by the number of taps.
 template <int BM, int BN, int WM, int WN, int EPI, bool NORM, int BK, int PREC, int KS = 1, bool SK = false, int MODE = 0>
-__global__ __launch_bounds__(256 * KS, (BK == 16 && KS == 1) ? (PREC == 3 ? 2 : (PREC == 0 && (BM <= 128 || MODE == 2) && BN <= 128 && !NORM && EPI != OFX_EPI_FLOW) ? 4 : 3) : 1) void igemm_kernel(const ConvK p) {
+__global__ __launch_bounds__(256 * KS, (BK == 16 && KS == 1) ? (PREC == 3 ? 2 : (PREC == 0 && BM <= 128 && BN <= 128 && !NORM && EPI != OFX_EPI_FLOW) ? 4 : 3) : 1) void igemm_kernel(const ConvK p) {
     constexpr bool UK = MODE == 1, PATCH = MODE == 2;
     // halo patch rows staged per channel slab, rounded up to whole groups of 16: 8x16 patches 12 x 16 / 10 x 18 / 8 x 20 -> 192,
     // 8x8 patches (the 64-row tile) 12 x 8 / 10 x 10 / 8 x 12 -> 112
@@ -281,7 +281,8 @@ __global__ __launch_bounds__(256 * KS, (BK == 16 && KS == 1) ? (PREC == 3 ? 2 : 
         constexpr int SROWS = 256 / QPR;                     // rows between a thread's consecutive slots
         // The 256-row tile keeps one pixel index per slot and forms the byte offset (pixel * row bytes of the slab's segment + the
         // thread's float4 slot) when a slab is issued -- a multiply per slot and slab instead of two resident offset tables: its six
-        // slots x two segments were registers it spilled at four workgroups per CU (28 -> 12-20 bytes of scratch).  The 128-row tiles
+        // slots x two segments were registers it spilled at four workgroups per CU (28 -> 12-20 bytes of scratch; since it measured level
+        // at three workgroups per CU -- 131 registers, nothing spilled -- it now runs there: no kernel of the step carries scratch).  The 128-row tiles
         // keep both tables: they fit, and forming offsets late cost the GRU z|r kernel a spill of its own.
         constexpr bool LAZY_OFF = BM == 256;
         int apixs[LAZY_OFF ? NSLOT : 1];

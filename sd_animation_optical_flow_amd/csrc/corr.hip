@@ -20,6 +20,7 @@
 
 #include <algorithm>
 #include <cstdlib>
+#include <type_traits>
 
 namespace {
 
@@ -130,6 +131,70 @@ __global__ __launch_bounds__(256) void pyramid_pool_kernel(const PoolArgs a) {
     }
     __syncthreads();
     store_blocked(s3, a.lv[3] + p * (long)a.slice[3], h3, w3, a.wb[3], a.slice[3]);
+}
+
+// Levels 2 and 3 from a blocked level 1, in registers (round 4).  A 4x8 block of level 1 is eight lanes' float4 (lane q: row q >> 1,
+// columns (q & 1) * 4 ..): it pools into a 2x4 patch of level 2 -- two 16-byte pieces of one level-2 block -- and that patch into a
+// 1x2 patch of level 3, with the partners two / one / four lanes away (DPP-free wave shuffles).  No LDS, no workgroup barrier, one
+// float4 per lane in, 16- and 8-byte stores out: a pure stream where the kernel above spends a workgroup with three barriers per
+// source pixel.  Same additions in the same order (((a + b) + c) + d) * 0.25 as avg_pool2d's window sum.  Needs every level tiled
+// by whole blocks that pool into whole patches: h1 % 16 == 0 and w1 % 32 == 0 (512x768 and 1024x1024 frames are).
+struct PoolRegArgs {
+    const float* l1;
+    float* l2;
+    float* l3;
+    int wb1, wb2, wb3;        // blocks per slice row of levels 1, 2, 3
+    int f4_per_slice;         // slice[1] / 4
+    int slice2, slice3;
+    long total;               // pixels * f4_per_slice
+    unsigned wps, mag_wps;    // waves per slice (f4_per_slice / 64) and ceil(2^32 / wps)
+    unsigned mag_wb1;         // ceil(2^32 / wb1)
+};
+
+__global__ __launch_bounds__(256) void pyramid_pool_reg_kernel(const PoolRegArgs a) {
+    typedef float f4v __attribute__((ext_vector_type(4)));
+    // a wave takes 64 consecutive float4 of one pixel's slice (a slice is a whole number of waves): the pixel and the wave's place in the
+    // slice are scalar, the two small divisions go through precomputed reciprocals
+    const int lane = threadIdx.x & 63;
+    const unsigned nwaves = (unsigned)(a.total >> 6);
+    auto body = [&](unsigned gw, const f4v v) __attribute__((always_inline)) {
+        const unsigned p = __umulhi(gw, a.mag_wps);                                                   // gw / (waves per slice)
+        const int e = (int)(gw - p * a.wps) * 64 + lane;
+        const int b = e >> 3, q = e & 7;
+        const int by = (int)__umulhi((unsigned)b, a.mag_wb1), bx = b - by * a.wb1;
+        // the row below (lane + 2): rows 0 / 2 of the block pool with rows 1 / 3
+        // (row_shl DPP moves: lane l reads lane l + n inside its row of 16 -- an 8-lane block never straddles a row; full-rate vector
+        // moves where wave shuffles would be twelve LDS-crossbar operations per lane)
+        auto up = [](float x, auto n) {
+            return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x100 + decltype(n)::value, 0xF, 0xF, true));
+        };
+        using std::integral_constant;
+        f4v d;
+        d.x = up(v.x, integral_constant<int, 2>{}); d.y = up(v.y, integral_constant<int, 2>{});
+        d.z = up(v.z, integral_constant<int, 2>{}); d.w = up(v.w, integral_constant<int, 2>{});
+        const float s0 = (((v.x + v.y) + d.x) + d.y) * 0.25f;     // level 2, columns bx * 4 + (q & 1) * 2 + {0, 1}  (valid on lanes with an even row)
+        const float s1 = (((v.z + v.w) + d.z) + d.w) * 0.25f;
+        // the right half of the row pair (lane + 1): lanes q = 0 and q = 4 assemble the 2x4 patch's rows
+        const float n0 = up(s0, integral_constant<int, 1>{}), n1 = up(s1, integral_constant<int, 1>{});
+        // level 3 from the patch: its second row sits four lanes up
+        const float u0 = up(s0, integral_constant<int, 4>{}), u1 = up(s1, integral_constant<int, 4>{});
+        const float un0 = up(n0, integral_constant<int, 4>{}), un1 = up(n1, integral_constant<int, 4>{});
+        if ((q & 3) == 0) {
+            const int y2 = (by << 1) + (q >> 2), x2 = bx << 2;                       // level-2 position of this piece: 4 columns of one row
+            const int i2 = ((((y2 >> 2) * a.wb2) + (x2 >> 3)) << 5) + ((y2 & 3) << 3) + (x2 & 7);
+            *reinterpret_cast<float4*>(a.l2 + (long)p * a.slice2 + i2) = make_float4(s0, s1, n0, n1);
+            if (q == 0 && a.l3) {
+                const int y3 = by, x3 = bx << 1;
+                const int i3 = ((((y3 >> 2) * a.wb3) + (x3 >> 3)) << 5) + ((y3 & 3) << 3) + (x3 & 7);
+                const float t0 = (((s0 + s1) + u0) + u1) * 0.25f, t1 = (((n0 + n1) + un0) + un1) * 0.25f;
+                *reinterpret_cast<float2*>(a.l3 + (long)p * a.slice3 + i3) = make_float2(t0, t1);
+            }
+        }
+    };
+    // one 1 KB load in flight per wave and trip (level 1 is read once, here: non-temporal); a second load a grid stride away measured
+    // SLOWER (0.70 against 0.63 ms: two distant streams per wave instead of one)
+    for (unsigned gw = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6)); gw < nwaves; gw += gridDim.x * 4)
+        body(gw, __builtin_nontemporal_load(reinterpret_cast<const f4v*>(a.l1) + ((long)gw * 64 + lane)));
 }
 
 // fmap rows (pixel order, [n][h*w][D]) -> blocked column order of the volume ([n][slice][D], zero rows for padding)
@@ -559,6 +624,21 @@ int ofx_corr_pool_launch(const float* l0, float* l1, float* l2, float* l3, int B
     }
     a.levels = levels;
     OFX_REQUIRE(a.h[1] > 0 && a.w[1] > 0, OFX_EINVAL);
+    static const bool no_reg = getenv("OFX_POOL_LDS") != nullptr;       // diagnostic: always the LDS kernel
+    if (from_l1 && !no_reg && a.h[1] % 16 == 0 && a.w[1] % 32 == 0 && levels >= 3 && l2 && (levels < 4 || l3)) {
+        PoolRegArgs r{};
+        r.l1 = l1; r.l2 = l2; r.l3 = levels >= 4 ? l3 : nullptr;
+        r.wb1 = a.wb[1]; r.wb2 = a.wb[2]; r.wb3 = a.wb[3];
+        r.f4_per_slice = a.slice[1] >> 2; r.slice2 = a.slice[2]; r.slice3 = a.slice[3];
+        r.total = (long)B * h * w * r.f4_per_slice;
+        r.wps = (unsigned)(r.f4_per_slice >> 6);                       // h1 % 16 == 0 and w1 % 32 == 0: the slice is a multiple of 512 floats
+        r.mag_wps = r.wps <= 1 ? 0u : (unsigned)(((1ull << 32) + r.wps - 1) / r.wps);
+        r.mag_wb1 = r.wb1 <= 1 ? 0u : (unsigned)(((1ull << 32) + r.wb1 - 1) / r.wb1);
+        OFX_REQUIRE((r.total >> 6) < (1L << 26) && r.wps >= 2 && r.wps <= 64 && r.wb1 >= 2 && r.wb1 <= 64, OFX_EINVAL);   // reciprocal divisions exact in this range
+        OfxProfScope prof("corr_pyramid_pool", s);
+        hipLaunchKernelGGL(pyramid_pool_reg_kernel, dim3((unsigned)std::min<long>((r.total + 255) / 256, 256L * 64)), dim3(256), 0, s, r);
+        return ofx_launch_status();
+    }
     const size_t lds = sizeof(float) * ((size_t)a.h[1] * a.w[1] + (size_t)a.h[2] * a.w[2] + (size_t)a.h[3] * a.w[3]);
     OFX_REQUIRE(lds <= 64 * 1024, OFX_EINVAL);
     OfxProfScope prof("corr_pyramid_pool", s);

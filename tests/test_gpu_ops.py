@@ -364,7 +364,7 @@ def test_conv2d_padded_cin_and_fused_instance_norm(cuda):
 # --------------------------------------------------------------------------------------
 # correlation
 # --------------------------------------------------------------------------------------
-@pytest.mark.parametrize("shape", [(2, 20, 16), (1, 24, 32), (1, 17, 19)])
+@pytest.mark.parametrize("shape", [(2, 20, 16), (1, 24, 32), (1, 17, 19), (2, 32, 64), (1, 96, 64)])   # the last two: every level in whole blocks -> levels 2, 3 by the register kernel
 def test_corr_volume_pyramid_and_lookup(cuda, shape):
     ops = _ops()
     B, h, w = shape

@@ -38,6 +38,12 @@ if os.environ.get("CONV_BENCH_B1"):
     ]
 
 
+if os.environ.get("CONV_BENCH_96"):      # the encoders' 96-channel stage at the bench batch (quarter resolution)
+    SHAPES = [
+        ("warm-up 3x3 256->192", 64, 96, 64, 256, 192, 3, 3, 1, 0),
+        ("enc 3x3 96->96 @1/4 B64", 64, 192, 128, 96, 96, 3, 3, 1, 0),
+    ]
+    TILES = [0, 16256096]
 if os.environ.get("CONV_BENCH_C1"):      # the motion encoder's 1x1 over the correlation channels, as laid out today and padded to whole chunks
     SHAPES = [
         ("warm-up 3x3 256->192", 64, 96, 64, 256, 192, 3, 3, 1, 0),

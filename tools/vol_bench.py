@@ -7,7 +7,7 @@ from sd_animation_optical_flow_amd import _lib
 if len(sys.argv) > 1:
     _lib.LIB_PATH = os.path.abspath(sys.argv[1])
 from sd_animation_optical_flow_amd import ops
-B, h, w, D = 64, 64, 96, 256
+B, h, w, D = 64, 96, 64, 256        # the bench geometry: 512x768 frames = 96 rows x 64 columns of features
 g = torch.Generator(device="cuda").manual_seed(0)
 f1 = torch.randn((B, h, w, D), device="cuda", generator=g)
 f2 = torch.randn((B, h, w, D), device="cuda", generator=g)
