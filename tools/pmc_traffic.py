@@ -21,7 +21,7 @@ FAMILIES = [
     ("igemm_conv_all", lambda n, gy: "igemm_kernel" in n and gy <= 1),
     ("corr_volume_gemm", lambda n, gy: "igemm_kernel" in n and gy > 1),
     ("corr_lookup", lambda n, gy: "corr_lookup" in n),
-    ("pyramid_pool", lambda n, gy: "pyramid_pool_kernel" in n),
+    ("pyramid_pool", lambda n, gy: "pyramid_pool" in n),
     ("upsample_warp", lambda n, gy: "upsample_warp_kernel" in n),
     ("upsample", lambda n, gy: "upsample_kernel" in n),
     ("flow_head", lambda n, gy: "flow_head_kernel" in n),
