@@ -128,3 +128,22 @@ def test_frame_writer_writes_every_frame_and_reports_failures(tmp_path):
     w.put(1, torch.zeros((12, 20), dtype=torch.uint8))          # not a [H,W,3] frame: the encoder thread raises ...
     with pytest.raises(ValueError):
         w.close()                                               # ... and flush / close re-raises it
+
+
+def test_png_writer_round_trips_through_pillow():
+    """`workspace.encode_png_rgb` (Sub filter + one zlib stream; what `put_ai_frame` writes) is a PNG any reader takes: Pillow decodes it
+    to the same pixels at every size / compression level, including one-pixel-wide and one-pixel-high images and level 0 (stored)."""
+    import io
+    from PIL import Image
+    from sd_animation_optical_flow_amd.workspace import encode_png_rgb
+    rng = np.random.default_rng(3)
+    for (h, w) in ((1, 1), (1, 7), (5, 1), (13, 17), (64, 96)):
+        img = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        for level in (0, 1, 6):
+            data = encode_png_rgb(img, level)
+            assert data[:8] == b"\x89PNG\r\n\x1a\n"
+            with Image.open(io.BytesIO(data)) as im:
+                assert im.mode == "RGB" and im.size == (w, h)
+                assert np.array_equal(np.asarray(im), img), (h, w, level)
+    flat = np.full((32, 32, 3), 200, dtype=np.uint8)                                  # a flat frame: the Sub filter makes it all zeros
+    assert len(encode_png_rgb(flat, 1)) < 200
