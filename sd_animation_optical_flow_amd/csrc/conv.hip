@@ -1149,8 +1149,8 @@ int launch_tile_uk(const ConvK& k, int epi, bool norm, int nz, hipStream_t s) {
             }
             return OFX_EINVAL;
         case kEpiVolPool:
-            if constexpr (BM == 128 && BN == 128 && BK == 16 && PREC == 0 && KS == 1 && !SK && UK != 2) {
-                hipLaunchKernelGGL((igemm_kernel<128, 128, 64, 64, kEpiVolPool, false, 16, 0, 1, false, UK>), grid, block, 0, s, k);
+            if constexpr (BM == 128 && BN == 128 && BK == 16 && KS == 1 && !SK && UK != 2) {
+                hipLaunchKernelGGL((igemm_kernel<128, 128, 64, 64, kEpiVolPool, false, 16, PREC, 1, false, UK>), grid, block, 0, s, k);
                 break;
             }
             return OFX_EINVAL;
@@ -1211,11 +1211,11 @@ int ofx_conv2d_stats(const ofx_conv_desc* d, float* part, size_t part_floats, in
 }
 
 // Correlation volume in the blocked layout + pyramid level 1 from the accumulators (corr.hip decides when it applies:
-// fp32, 128x128 tiles, h % 8 == 0 and w % 16 == 0 so that level 1 is tiled by whole blocks).  pool_out: level 1,
+// 128x128 tiles, h % 8 == 0 and w % 16 == 0 so that level 1 is tiled by whole blocks; any arithmetic).  pool_out: level 1,
 // [nz][M][slice1]; wb0 / wb1: blocks per slice row of level 0 / 1.
 int ofx_conv2d_volpool(const ofx_conv_desc* d, float alpha, float* pool_out, long pool_zs, int wb0, int wb1, int slice1, void* stream) {
     OFX_REQUIRE(d && pool_out && wb0 > 0 && wb1 > 0 && slice1 > 0, OFX_EINVAL);
-    OFX_REQUIRE(d->precision == OFX_PREC_FP32 && d->epi == OFX_EPI_PLAIN && d->act == OFX_ACT_NONE && !d->res && !d->addend && !d->nmean &&
+    OFX_REQUIRE(d->epi == OFX_EPI_PLAIN && d->act == OFX_ACT_NONE && !d->res && !d->addend && !d->nmean &&
                     !d->scale && !d->shift && d->Cout % 128 == 0 && d->tile == 0,
                 OFX_EINVAL);
     tl_pool.on = true; tl_pool.out = pool_out; tl_pool.zs = pool_zs; tl_pool.wb0 = wb0; tl_pool.wb1 = wb1; tl_pool.slice1 = slice1;
@@ -1418,21 +1418,25 @@ extern "C" int ofx_conv2d_alpha(const ofx_conv_desc* d, float alpha, void* strea
         k.mtiles = (int)(M / 256);
     } else
     if (k.patch && !whole) k.mtiles = d->B * ((d->Hin + ph - 1) / ph) * ((d->Win + 15) / 16);
-    // statistics from the accumulators (ofx_conv2d_stats): raw outputs only, tiles that stay inside one image
+    // statistics from the accumulators (ofx_conv2d_stats): raw outputs only, tiles that stay inside one image.  Called once the tile
+    // of the launch is final (the split-bf16 modes remap it below).
     k.stats = nullptr;
-    if (tl_stats.on) {
+    auto setup_stats = [&](int tbm, int tbn) {
+        k.stats = nullptr;
+        if (!tl_stats.on) return;
         tl_stats.rows_per_image = 0;
-        const int waves_m = (bm == 256 && bn == 64) ? 4 : (bm == 128 && (bn == 128 || bn == 64 || bn == 192)) ? 2 : (bm == 128 && (bn == 96 || bn == 32)) ? 4
-                            : (bm == 64 && bn == 64) ? 2 : 0;
+        const int waves_m = (tbm == 256 && tbn == 64) ? 4 : (tbm == 128 && (tbn == 128 || tbn == 64 || tbn == 192)) ? 2 : (tbm == 128 && (tbn == 96 || tbn == 32)) ? 4
+                            : (tbm == 64 && tbn == 64) ? 2 : 0;
         const long hw = (long)d->Hout * d->Wout;
-        const bool ok = waves_m && d->precision == OFX_PREC_FP32 && d->epi == OFX_EPI_PLAIN && d->act == OFX_ACT_NONE && !d->res && nz == 1 &&
-                        k.mtiles % d->B == 0 && (k.patch || hw % bm == 0);
+        const bool ok = waves_m && d->epi == OFX_EPI_PLAIN && d->act == OFX_ACT_NONE && !d->res && nz == 1 &&
+                        k.mtiles % d->B == 0 && (k.patch || hw % tbm == 0);
         const long rows = ok ? (long)(k.mtiles / d->B) * waves_m : 0;
         if (ok && (size_t)d->B * rows * d->Cout * 2 <= tl_stats.cap_floats) {
             k.stats = tl_stats.part;
             tl_stats.rows_per_image = (int)rows;
         }
-    }
+    };
+    if (d->precision == OFX_PREC_FP32) setup_stats(bm, bn);
 #ifdef OFX_CONV_LEAN   // experiment builds (tools/build_variant.sh): fp32 only -- a third of the instantiations, a third of the compile time
     if (d->precision != OFX_PREC_FP32) return OFX_EINVAL;
 #else
@@ -1451,6 +1455,16 @@ extern "C" int ofx_conv2d_alpha(const ofx_conv_desc* d, float alpha, void* strea
                    bm == 128 && tile_bk != 32 && d->epi != OFX_EPI_FLOW)
                       ? 1 : 0;
         k.mtiles = k.patch && !whole16 ? d->B * ((d->Hin + 7) / 8) * ((d->Win + 15) / 16) : (int)((M + bm - 1) / bm);
+        setup_stats(bm, bn);
+        if (tl_pool.on) {   // the blocked correlation volume with pyramid level 1 out of the accumulators, in the split arithmetic
+            k.mtiles = (int)((M + 127) / 128);
+            k.ntiles = (d->Cout + 127) / 128;
+            k.group_m = k.ntiles >= 8 ? 8 : 1;
+            k.ksplit = 1;
+            if (d->precision == OFX_PREC_BF16X6) return launch_tile<128, 128, 64, 64, 16, 3>(k, kEpiVolPool, false, nz, s);
+            if (d->precision == OFX_PREC_BF16X3_W) return launch_tile<128, 128, 64, 64, 16, 2>(k, kEpiVolPool, false, nz, s);
+            return launch_tile<128, 128, 64, 64, 16, 1>(k, kEpiVolPool, false, nz, s);
+        }
         if (d->precision == OFX_PREC_BF16X6) {
             if (bm == 128 && bn == 128) return launch_tile<128, 128, 64, 64, 16, 3>(k, d->epi, norm, nz, s);
             if (bm == 128 && bn == 64) return launch_tile<128, 64, 64, 32, 16, 3>(k, d->epi, norm, nz, s);

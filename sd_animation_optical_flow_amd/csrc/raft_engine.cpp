@@ -862,9 +862,9 @@ static int raft_forward_impl(ofx_raft* r, const uint8_t* image1, const uint8_t* 
         d.act = OFX_ACT_NONE; d.epi = OFX_EPI_PLAIN;
         d.precision = prec;
         // zero batch strides broadcast a shared key-frame feature map across the batch.  Level 1 of the pyramid comes out
-        // of the GEMM's accumulators when it can (fp32, whole-block level 1): level 0 is then never read back
+        // of the GEMM's accumulators when it can (whole-block level 1): level 0 is then never read back
         const long slice1 = ofx_corr_slice_floats_l(h >> 1, w >> 1);
-        const bool fused = prec == OFX_PREC_FP32 && ofx_corr_volpool_ok(h, w) && Nb % 128 == 0 && N * slice1 * 4 < (1L << 31) - 64;
+        const bool fused = ofx_corr_volpool_ok(h, w) && Nb % 128 == 0 && N * slice1 * 4 < (1L << 31) - 64;   // (every arithmetic since round 4)
         if (fused)
             st = ofx_conv2d_volpool(&d, 1.0f / std::sqrt((float)FD), ws.pyr[1], N * slice1, (w + 7) >> 3, ((w >> 1) + 7) >> 3, (int)slice1, s);
         else
@@ -971,7 +971,7 @@ int ofx_raft_forward_pairs_warp(ofx_raft* r, const uint8_t* images, int n_images
     st = ofx_corr_block_rows(ws.fmap1, ws.fmap2b, n_images, h, w, FD, s);   // every image can be an image2: blocked copy of all
     if (st) return st;
     const long slice1p = ofx_corr_slice_floats_l(h >> 1, w >> 1);
-    const bool fused_pairs = prec == OFX_PREC_FP32 && ofx_corr_volpool_ok(h, w) && Nb % 128 == 0 && N * slice1p * 4 < (1L << 31) - 64;
+    const bool fused_pairs = ofx_corr_volpool_ok(h, w) && Nb % 128 == 0 && N * slice1p * 4 < (1L << 31) - 64;
     for (int b = 0; b < B && !st; ++b) {   // one N x Nb correlation GEMM per pair, straight from the shared feature maps
         ofx_conv_desc d{};
         d.in0 = ws.fmap1 + (long)idx1[b] * N * FD; d.ld0 = FD; d.c0 = FD;
