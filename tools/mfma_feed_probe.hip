@@ -6,7 +6,7 @@
 #include <cstdio>
 typedef float v16f __attribute__((ext_vector_type(16)));
 
-template <int NB, int FEED>   // FEED 0: registers, 1: A from LDS, 2: A and B from LDS
+template <int NB, int FEED, int ACC = 0>   // FEED 0: registers, 1: A from LDS, 2: A and B from LDS; ACC 1: accumulators in AGPRs (inline asm)
 __global__ __launch_bounds__(256) void probe(float* out, int iters) {
     __shared__ __attribute__((aligned(16))) float lds[4 * 64 * 20 * 2 + 64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -34,13 +34,15 @@ __global__ __launch_bounds__(256) void probe(float* out, int iters) {
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int r = 0; r < NB / 16; ++r) {
+#define MF(C, A, B) \
+            if constexpr (ACC == 0) C = __builtin_amdgcn_mfma_f32_32x32x2f32(A, B, C, 0, 0, 0); \
+            else if constexpr (ACC == 1) asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+a"(C) : "v"(A), "v"(B)); \
+            else asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+v"(C) : "v"(A), "v"(B));
 #define STEP(S)                                                                          \
-            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0].S, b[0].S, acc[0], 0, 0, 0);      \
-            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0].S, b[1].S, acc[1], 0, 0, 0);      \
-            acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[1].S, b[0].S, acc[2], 0, 0, 0);      \
-            acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[1].S, b[1].S, acc[3], 0, 0, 0);
+            MF(acc[0], a[0].S, b[0].S) MF(acc[1], a[0].S, b[1].S) MF(acc[2], a[1].S, b[0].S) MF(acc[3], a[1].S, b[1].S)
             STEP(x) STEP(y) STEP(z) STEP(w)
 #undef STEP
+#undef MF
         }
         __builtin_amdgcn_sched_barrier(0);
         a[0] = an[0]; a[1] = an[1]; b[0] = bn[0]; b[1] = bn[1];
@@ -51,7 +53,7 @@ __global__ __launch_bounds__(256) void probe(float* out, int iters) {
     out[blockIdx.x * 256 + threadIdx.x] = s;
 }
 
-template <int NB, int FEED>
+template <int NB, int FEED, int ACC = 0>
 static void run(const char* what, float* out) {
     hipEvent_t e0, e1;
     hipEventCreate(&e0);
@@ -59,10 +61,10 @@ static void run(const char* what, float* out) {
     const int iters = 20000 * 16 / NB;
     for (int wg = 1; wg <= 4; wg *= 2) {
         const int grid = 256 * wg;
-        hipLaunchKernelGGL((probe<NB, FEED>), dim3(grid), dim3(256), 0, 0, out, 100);
+        hipLaunchKernelGGL((probe<NB, FEED, ACC>), dim3(grid), dim3(256), 0, 0, out, 100);
         hipDeviceSynchronize();
         hipEventRecord(e0);
-        hipLaunchKernelGGL((probe<NB, FEED>), dim3(grid), dim3(256), 0, 0, out, iters);
+        hipLaunchKernelGGL((probe<NB, FEED, ACC>), dim3(grid), dim3(256), 0, 0, out, iters);
         hipEventRecord(e1);
         hipEventSynchronize(e1);
         float ms;
@@ -81,5 +83,11 @@ int main() {
     run<32, 1>("A from LDS", out);
     run<32, 2>("A and B from LDS", out);
     run<48, 2>("A and B from LDS", out);
+    run<16, 0, 1>("registers, AGPR acc", out);
+    run<16, 2, 1>("A and B from LDS, AGPR acc", out);
+    run<32, 2, 1>("A and B from LDS, AGPR acc", out);
+    run<16, 0, 2>("registers, VGPR acc", out);
+    run<16, 2, 2>("A and B from LDS, VGPR acc", out);
+    run<32, 2, 2>("A and B from LDS, VGPR acc", out);
     return 0;
 }
