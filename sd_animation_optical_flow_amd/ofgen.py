@@ -6,7 +6,7 @@ Same names, argument meaning and mutation behaviour as the reference functions t
     RAFT_2().calc(img1_bgr, img2_bgr) -> flow        ofgen_keyframe_inpaint.py:47-71 ; ofgen.py:55-79
     warp_frame(frame, flow)          (RAFT convention) ofgen_keyframe_inpaint.py:92-98
     warp_frame_latent(latent, flow)                  ofgen_keyframe_inpaint.py:100-111
-    of_calc(frame1, frame2, algo)                    ofgen_keyframe_inpaint.py:113-133
+    of_calc(frame1, frame2, algo)                    ofgen_keyframe_inpaint.py:113-133 ; ofgen.py:45-49 (bare-flow algo -> (flow, v))
     generate_mask(conf, log_conf, thres)             ofgen_keyframe_inpaint.py:317-322  (mutates log_conf)
     create_mask_aux / confidence_to_mask             ofgen_keyframe_inpaint.py:237-248, 292-304
     mix_propagated_ai_frame                          ofgen_keyframe_inpaint.py:306-315
@@ -102,13 +102,24 @@ def warp_frame_latent(latent: torch.Tensor, flow, mode: Optional[str] = None, de
 
 
 def of_calc(frame1, frame2, algo, verbose: bool = False):
-    """ofgen_keyframe_inpaint.py:113-133: (flow, confidence, v, log_confidence); v = |flow| with
-    v[confidence < 0.9] = 0."""
-    flow, confidence, log_confidence = algo.calc(frame1, frame2)
-    v = ops.travel_distance(_dev(flow)[None], _dev(confidence)[None], 0.9)[0].cpu().numpy()
-    if verbose:
-        print("v.max()", v.max(), "v.min()", v.min())
-    return flow, confidence, v, log_confidence
+    """Both of the reference's `of_calc`s, told apart by what `algo.calc` returns:
+
+    * a PDCNet-style algo (`calc -> (flow, confidence, log_confidence)`): ofgen_keyframe_inpaint.py:113-133 --
+      `(flow, confidence, v, log_confidence)`, v = |flow| with v[confidence < 0.9] = 0;
+    * a RAFT-style algo (`calc -> flow`, e.g. this module's `RAFT_2`): ofgen.py:45-49, the live caller at ofgen.py:137 --
+      `(flow, v)`, v = sqrt(fx*fx + fy*fy) everywhere."""
+    res = algo.calc(frame1, frame2)
+    if isinstance(res, (tuple, list)):
+        flow, confidence, log_confidence = res
+        v = ops.travel_distance(_dev(flow)[None], _dev(confidence)[None], 0.9)[0].cpu().numpy()
+        if verbose:
+            print("v.max()", v.max(), "v.min()", v.min())
+        return flow, confidence, v, log_confidence
+    flow = np.asarray(res, np.float32)
+    fl = _dev(flow)[None]
+    ones = torch.ones(fl.shape[:3], dtype=torch.float32, device=fl.device)     # no confidence floor in this variant
+    v = ops.travel_distance(fl, ones, 0.9)[0].cpu().numpy()
+    return res, v
 
 
 def generate_mask(cum_confidence: np.ndarray, log_confidence: np.ndarray, thres: float = 0.8, ksize: int = 7):

@@ -122,6 +122,15 @@ def test_of_calc_and_raft2(cuda, raft_sd, algo):
     g1, g2 = _pair(6)
     flow, conf, v, logc = ofgen.of_calc(g1, g2, algo)
     assert np.array_equal(v, MO.travel_distance(flow, conf))
+    # the RAFT-variant of_calc (reference ofgen.py:45-49, live caller :137): an algo whose calc returns a bare flow -> (flow, v),
+    # v = sqrt(fx*fx + fy*fy) with no confidence floor
+    out = ofgen.of_calc(f1, f2, r2)
+    assert isinstance(out, tuple) and len(out) == 2
+    flow2, v2 = out
+    assert flow2.shape == (104, 96, 2) and v2.shape == (104, 96) and v2.dtype == np.float32
+    fx, fy = flow2[:, :, 0], flow2[:, :, 1]
+    assert np.array_equal(v2, np.sqrt(fx * fx + fy * fy))
+    assert np.array_equal(flow2, flo)
 
 
 def test_compose_greedy_multi_reference(cuda):
