@@ -38,6 +38,7 @@ if ROOT not in sys.path:
 H, W = 768, 512                 # "512x768" = W x H (SURVEY conventions)
 ITERS = 20
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: 8.0 TB/s spec
+HBM_ACHIEVABLE_GBS = 6300.0     # same guide: what a well-formed streaming kernel reaches on this part (~0.79 of the spec)
 MFMA_F32_PEAK_TFLOPS = 157.3    # v_mfma_f32_32x32x2_f32 dense peak
 
 
@@ -319,6 +320,8 @@ def main():
     ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16x3", "bf16x6"],
                     help="matrix-core arithmetic of the timed run (fp32 = the reference's; bf16x3 = opt-in split-bf16 fast mode)")
     ap.add_argument("--no-fast", action="store_true", help="skip the secondary bf16x3 measurement")
+    ap.add_argument("--no-sweep", action="store_true", help="skip the small-batch sweep (B = 1, 4, 16 frames per call)")
+    ap.add_argument("--no-pipeline", action="store_true", help="skip the workspace pipeline measurement (PNG in -> ClipPipeline.run -> PNG out)")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--verify-npz", default=None, help=argparse.SUPPRESS)
     ap.add_argument("--verify-only", action="store_true", help=argparse.SUPPRESS)
@@ -485,8 +488,8 @@ def main():
                 per = work[key_bytes] / (c / steps)
                 gbs = per / (m / c * 1e-3) / 1e9
                 ks[label] = {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                             "frac": round(gbs / HBM_PEAK_GBS, 4), "bytes_per_launch": per, "avg_launch_ms": round(m / c, 4),
-                             "launches_per_step": c // steps}
+                             "frac": round(gbs / HBM_PEAK_GBS, 4), "frac_of_achievable": round(gbs / HBM_ACHIEVABLE_GBS, 4),
+                             "bytes_per_launch": per, "avg_launch_ms": round(m / c, 4), "launches_per_step": c // steps}
         hbm("igemm_corr_volume", "volume_bytes", "corr_volume_gemm")
         hbm("corr_pyramid_pool", "pool_bytes", "corr_pyramid_pool")
         work["lookup_total"] = work["lookup_bytes"] * ITERS
@@ -589,6 +592,26 @@ def main():
                                               "frac": round(tf1 / MFMA_F32_PEAK_TFLOPS, 4), "flops_executed": cf,
                                               "note": "executed convolution FLOPs / wall time of the whole call (flow + warp + mask)"}
 
+    if not args.no_sweep and not args.no_single and world == 1 and B >= 16:
+        # the batches between configs[1] and configs[2]: what a frame-by-frame caller (B = 1, the reference's README path), a
+        # forward-backward `calc` (2), `PDCNetAux`'s batches (16, ofgen_keyframe_inpaint.py:1128) and short segments see
+        sweep = [{"B": 1, "ms": out["single_pair"]["ms"], "pairs_per_s": out["single_pair"]["pairs_per_s"]}]
+        for bs in (4, 16):
+            sstep = make_step(eng, frames[:bs].contiguous(), key, key_ai, conf[:bs].contiguous(), args.warp_mode, args.separate_warp)
+            for _ in range(2):
+                sstep()
+            torch.cuda.synchronize()
+            reps = 5 if bs <= 4 else 3
+            t1 = time.perf_counter()
+            for _ in range(reps):
+                sstep()
+            torch.cuda.synchronize()
+            dts = (time.perf_counter() - t1) / reps
+            sweep.append({"B": bs, "ms": round(dts * 1e3, 3), "pairs_per_s": round(bs / dts, 2)})
+            del sstep
+        sweep.append({"B": B, "ms": round(ms_per_step, 3), "pairs_per_s": round(B / ms_per_step * 1e3, 2)})
+        out["batch_sweep"] = sweep
+
     if not args.no_fast and world == 1 and args.precision == "fp32":
         # `ofgen.RAFT_2` AS WRITTEN (the reference never calls .eval(): context-encoder BatchNorm on each image's own statistics,
         # ofgen_keyframe_inpaint.py:47-60) on the same clip and the same step: a second copy of the context encoder without folded
@@ -661,6 +684,23 @@ def main():
                              "flow_epe_vs_fp32_px": epe, "flow_max_err_vs_fp32_px": emax, "note": note}
             del fast
         del ref_flow
+
+    if not args.no_pipeline and world == 1 and args.precision == "fp32":
+        # the path end to end over a workspace (SURVEY 8e names a rank's host side as the scaling limit): PNGs on disk -> decode ->
+        # H2D -> flow both ways + confidence -> warp + mask -> SD-inpaint inputs -> render -> D2H -> PNGs on disk, against the same
+        # calls on resident frames.  Needs a writable temp dir; never `value` (inputs of `value` are resident in HBM).
+        import tempfile
+        try:
+            with tempfile.TemporaryDirectory(prefix="ofx_probe_"):
+                pass
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import pipeline_rate
+            wp = pipeline_rate.measure(128, None, reps=1, inline=False)
+            wp["one_batch_share"] = {k: v for k, v in pipeline_rate.measure(64, None, reps=1, inline=False).items()
+                                     if k in ("frames", "end_to_end_fps", "device_only_fps", "ratio", "host_cpu_s_per_frame", "edge_batch")}
+            out["workspace_pipeline"] = wp
+        except Exception as e:                                   # read-only or missing temp dir, Pillow absent ...: report, do not fail the bench
+            out["workspace_pipeline"] = {"error": repr(e)[:200]}
 
     # child process with a hard time limit: neither the baseline nor the check may take the GPU number down with them
     import subprocess

@@ -16,7 +16,7 @@
  *   ofx_upsample_flow           RAFT/core/raft.py:72-83
  *   ofx_raft_*                  RAFT/core/raft.py:86-144 ; ofgen_keyframe_inpaint.py:47-71 (RAFT_2)
  *   ofx_warp_*                  pdcnet_of.py:34-42 ; ofgen_keyframe_inpaint.py:92-98 (cv2.remap)
- *   ofx_generate_mask, ofx_dilate_u8, ofx_expand_mask, ofx_travel_distance, ofx_merge_images,
+ *   ofx_generate_mask, ofx_dilate_u8, ofx_expand_mask, ofx_travel_distance, ofx_flow_magnitude, ofx_merge_images,
  *   ofx_mix_frames, ofx_conf_sum
  *   ofx_groupnorm, ofx_softmax_rows, ofx_attention_f32
  *                               ldm/modules/diffusionmodules/model.py:35-41,152-203 ; ldm/modules/attention.py:314,426
@@ -88,6 +88,9 @@ int ofx_expand_mask(const uint8_t* mask, const uint8_t* image_bgr, uint8_t* out,
 /* v = |flow| with v[conf < conf_floor] = 0 (of_calc, ofgen_keyframe_inpaint.py:118-126) */
 int ofx_travel_distance(const float* flow, const float* conf, float* out, int B, int H, int W,
                         float conf_floor, void* stream);
+/* The RAFT-variant of_calc (reference ofgen.py:45-49, caller :137): v = sqrt(fx*fx + fy*fy) of a bare flow, n pixels; f32
+ * multiply, multiply, add (no contraction) and a correctly rounded square root: numpy's bits. */
+int ofx_flow_magnitude(const float* flow, float* out, long n, void* stream);
 /* confidence_to_mask (:237-248): travel' = warp(travel, flow) + dist; travel'[conf<0.9] = 0;
  * raw = 255*(conf<0.9 | travel' > thres); travel'[travel'>thres] = 0.  `raw` is un-dilated; the
  * caller dilates with ofx_dilate_u8(ksize=15). travel_in and travel_out must not alias. */
@@ -181,7 +184,9 @@ int ofx_abs_diff_sum_u8(const uint8_t* a, long a_bstride, const uint8_t* b, long
 #define OFX_EPI_PLAIN   0   /* y = act(acc*scale + shift); if res: y = relu(y + res)            */
 #define OFX_EPI_GRU_ZR  1   /* Cout=2*hd: n<hd -> z=sigmoid -> aux_z ; n>=hd -> r -> aux_rh=r*h   */
 #define OFX_EPI_GRU_Q   2   /* q=tanh; h = (1-z)*h + z*q written in place to aux_h               */
-#define OFX_EPI_FLOW    3   /* Cout=2: coords1 += delta; flow=coords1-grid -> aux_h slot + flow4 */
+#define OFX_EPI_FLOW    3   /* Cout=2: coords1 += delta; flow=coords1-grid -> aux_h slot + flow4.  The generic form of the flow
+                               head's second convolution; the RAFT executor itself runs flow_head.hip, which leaves convf1's
+                               operand as 16-float flow rows instead of this [M][4] array */
 
 /* Arithmetic of the matrix-core contractions.  FP32 is the reference's (and the default): v_mfma_f32_32x32x2_f32,
  * bit-identical to an fmaf chain.  BF16X3 is an opt-in fast mode: each fp32 operand is split on the fly into
@@ -207,7 +212,7 @@ typedef struct ofx_conv_desc {
     const float* nmean; const float* nrstd;      /* instance-norm(+ReLU) applied to in0 on load, [B][c0], or NULL */
     const float* addend; int ldadd;              /* optional pre-activation term: v += addend[m*ldadd + n]       */
     float* aux_z; float* aux_rh; float* aux_h; int ldh;   /* GRU buffers; hidden dim = Cout(Q) */
-    float* aux_coords; float* aux_flow4;         /* EPI_FLOW state: coords1 [M][2], flow4 [M][4] */
+    float* aux_coords; float* aux_flow4;         /* EPI_FLOW only: coords1 [M][2], flow4 [M][4] = (fx, fy, 0, 0) per pixel */
     long a_zs, w_zs, o_zs; int nz;               /* batched-GEMM mode (nz>1): per-z strides in elements */
     int B, Hin, Win, Hout, Wout, Cout, KH, KW, stride, padH, padW;
     int act, epi;

@@ -65,6 +65,7 @@ SIGNATURES = {
     "ofx_dilate_u8": (_i, [_p, _p, _i, _i, _i, _i, _p]),
     "ofx_expand_mask": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "ofx_travel_distance": (_i, [_p, _p, _p, _i, _i, _i, _f, _p]),
+    "ofx_flow_magnitude": (_i, [_p, _p, _l, _p]),
     "ofx_travel_mask": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _f, _i, _p]),
     "ofx_merge_images": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _p]),
     "ofx_mix_frames": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _f, _p]),

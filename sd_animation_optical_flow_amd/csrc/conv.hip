@@ -1342,10 +1342,27 @@ extern "C" int ofx_conv2d_alpha(const ofx_conv_desc* d, float alpha, void* strea
         else if (waste(32) < waste(64) - 0.1) bn = 32;
         else bn = 64;
         bm = 128;
-        const long blocks128 = ((M + 127) / 128) * ((d->Cout + bn - 1) / bn) * nz;
-        if (bn == 96 && blocks128 < 1024) bn = 32;   // no small-grid variant of the 96-wide tile
-        if (bn >= 64 && blocks128 < 1024) bm = 64;   // under ~4 waves of 256 CUs: smaller tiles fill the chip
-        if (bm == 64 && bn >= 128) bn = 64;
+        // Grids that do not fill the chip (B = 1 ... ~16 frames at 512x768).  Measured over every layer shape of the network at
+        // B = 1, 2, 4, 8, 16, 32 (tools/small_batch_tune.py, profiles/r05_small_batch_tune.txt): a 128-row tile keeps its rate down
+        // to THREE workgroups per CU (768 on this part) and loses to the next smaller tile below that -- so take the largest tile
+        // whose grid still has 768 workgroups: 128x192 -> 128x96 -> 128x64 for the 192-channel layer, 128x128 -> 128x64 for the
+        // 128- / 256-channel ones, and only then the 64x64 small-grid tile (with split-K / paired pipelines below).  The old rule
+        // (64x64 below 1024 blocks of the 128-row tile) gave up 8-16 % per layer at B = 4 ... 16.
+        const long mt128 = (M + 127) / 128;
+        auto blocks_of = [&](int t) { return mt128 * ((d->Cout + t - 1) / t) * nz; };
+        static const bool old_small = getenv("OFX_CONV_OLD_SMALL_TILES") != nullptr;      // A/B switch: the round-4 rule
+        constexpr long kFill = 768;                  // three workgroups per CU
+        const long blocks128 = blocks_of(bn);
+        if (old_small) {
+            if (bn == 96 && blocks128 < 1024) bn = 32;
+            if (bn >= 64 && blocks128 < 1024) bm = 64;
+            if (bm == 64 && bn >= 128) bn = 64;
+        } else if (bn >= 64 && blocks128 < kFill) {
+            if (bn == 192 && d->epi == OFX_EPI_PLAIN && blocks_of(96) >= kFill) bn = 96;
+            else if (bn >= 128 && blocks_of(64) >= kFill) bn = 64;
+            else if (bn == 96) bn = 32;              // no small-grid variant of the 96-wide tile
+            else { bm = 64; bn = 64; }               // 64x64: the chip is filled by splitting K instead (below)
+        }
     }
     k.mtiles = (int)((M + bm - 1) / bm);
     k.ntiles = (d->Cout + bn - 1) / bn;
@@ -1395,8 +1412,10 @@ extern "C" int ofx_conv2d_alpha(const ofx_conv_desc* d, float alpha, void* strea
     // uniform-K fast path: every chunk of this launch's BK inside one tap and one segment (the 16-float flow rows of convf1 qualify
     // with BK = 16; a caller-forced tile keeps the conservative multiple-of-32 rule)
     static const bool no_uk = getenv("OFX_CONV_NO_UK") != nullptr;
+    // (`bk` is the BK of the fp32 tile launched below; the split-bf16 remap further down changes tiles, but launch_tile takes the
+    // scalar-coordinate schedule for PREC == 0 only, so `uk` is never read for a tile it was not derived from)
     const int ukm = d->tile ? 32 : bk;
-    k.uk = (!no_uk && k.cin % ukm == 0 && (d->c1 == 0 || d->c0 % ukm == 0)) ? 1 : 0;
+    k.uk = (!no_uk && d->precision == OFX_PREC_FP32 && k.cin % ukm == 0 && (d->c1 == 0 || d->c0 % ukm == 0)) ? 1 : 0;
     // halo-patch kernel: stride-1 3x3 / 1x5 / 5x1, "same" padding, the map a whole number of 8x16 patches, whole 16-channel slabs
     static const bool no_patch = getenv("OFX_CONV_NO_PATCH") != nullptr;
     const bool shape_ok = (d->KH == 3 && d->KW == 3) || (d->KH == 1 && d->KW == 5) || (d->KH == 5 && d->KW == 1);
@@ -1411,9 +1430,11 @@ extern "C" int ofx_conv2d_alpha(const ofx_conv_desc* d, float alpha, void* strea
                (d->c1 == 0 || d->c0 % bk == 0) && (!d->nmean || d->c1 == 0) && nz == 1 && (big || small) &&
                (bn == 64 || bn == 96 || bn == 128 || bn == 192) && d->epi != OFX_EPI_FLOW)
                   ? 1 : 0;
-    if (k.patch && bm == 128 && bn == 64 && d->tile == 0 && d->Hin % 16 == 0 && d->Win % 16 == 0 && M / 256 >= 4096) {
-        // 64-channel layers on large maps: 16x16 patches (256x64 tile, 64x64 per wave) halve the weight staging per MFMA:
-        // 136 -> 139-143 TF on grids of four rounds or more (it loses on shorter grids: the tail is twice as coarse)
+    static const bool old_p256 = getenv("OFX_CONV_OLD_SMALL_TILES") != nullptr;
+    if (k.patch && bm == 128 && bn == 64 && d->tile == 0 && d->Hin % 16 == 0 && d->Win % 16 == 0 && M / 256 >= (old_p256 ? 4096 : 768)) {
+        // 64-channel layers: 16x16 patches (256x64 tile, 64x64 per wave) halve the weight staging per MFMA: 136 -> 139-143 TF on
+        // large grids, and ahead of the 128x64 tile from three workgroups per CU on (round 5 sweep: 110 vs 133 us at 768
+        // workgroups, 217 vs 232 at 1536; round 4 switched at 4096)
         bm = 256;
         k.mtiles = (int)(M / 256);
     } else

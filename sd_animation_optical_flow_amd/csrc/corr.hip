@@ -135,7 +135,7 @@ __global__ __launch_bounds__(256) void pyramid_pool_kernel(const PoolArgs a) {
 
 // Levels 2 and 3 from a blocked level 1, in registers (round 4).  A 4x8 block of level 1 is eight lanes' float4 (lane q: row q >> 1,
 // columns (q & 1) * 4 ..): it pools into a 2x4 patch of level 2 -- two 16-byte pieces of one level-2 block -- and that patch into a
-// 1x2 patch of level 3, with the partners two / one / four lanes away (DPP-free wave shuffles).  No LDS, no workgroup barrier, one
+// 1x2 patch of level 3, with the partners two / one / four lanes away (row_shl DPP moves, no ds_bpermute).  No LDS, no workgroup barrier, one
 // float4 per lane in, 16- and 8-byte stores out: a pure stream where the kernel above spends a workgroup with three barriers per
 // source pixel.  Same additions in the same order (((a + b) + c) + d) * 0.25 as avg_pool2d's window sum.  Needs every level tiled
 // by whole blocks that pool into whole patches: h1 % 16 == 0 and w1 % 32 == 0 (512x768 and 1024x1024 frames are).
@@ -625,16 +625,21 @@ int ofx_corr_pool_launch(const float* l0, float* l1, float* l2, float* l3, int B
     a.levels = levels;
     OFX_REQUIRE(a.h[1] > 0 && a.w[1] > 0, OFX_EINVAL);
     static const bool no_reg = getenv("OFX_POOL_LDS") != nullptr;       // diagnostic: always the LDS kernel
-    if (from_l1 && !no_reg && a.h[1] % 16 == 0 && a.w[1] % 32 == 0 && levels >= 3 && l2 && (levels < 4 || l3)) {
+    // register kernel: whole blocks at every level, and wave / block-row counts inside the range in which its reciprocal
+    // divisions are exact -- every other shape (tiny or very wide maps included) takes the LDS kernel below
+    const long reg_f4 = a.slice[1] >> 2, reg_total = (long)B * h * w * reg_f4;
+    const long reg_wps = reg_f4 >> 6;
+    const bool reg_ok = from_l1 && !no_reg && a.h[1] % 16 == 0 && a.w[1] % 32 == 0 && levels >= 3 && l2 && (levels < 4 || l3) &&
+                        (reg_total >> 6) < (1L << 26) && reg_wps >= 2 && reg_wps <= 64 && a.wb[1] >= 2 && a.wb[1] <= 64;
+    if (reg_ok) {
         PoolRegArgs r{};
         r.l1 = l1; r.l2 = l2; r.l3 = levels >= 4 ? l3 : nullptr;
         r.wb1 = a.wb[1]; r.wb2 = a.wb[2]; r.wb3 = a.wb[3];
         r.f4_per_slice = a.slice[1] >> 2; r.slice2 = a.slice[2]; r.slice3 = a.slice[3];
-        r.total = (long)B * h * w * r.f4_per_slice;
-        r.wps = (unsigned)(r.f4_per_slice >> 6);                       // h1 % 16 == 0 and w1 % 32 == 0: the slice is a multiple of 512 floats
+        r.total = reg_total;
+        r.wps = (unsigned)reg_wps;                                     // h1 % 16 == 0 and w1 % 32 == 0: the slice is a multiple of 512 floats
         r.mag_wps = r.wps <= 1 ? 0u : (unsigned)(((1ull << 32) + r.wps - 1) / r.wps);
         r.mag_wb1 = r.wb1 <= 1 ? 0u : (unsigned)(((1ull << 32) + r.wb1 - 1) / r.wb1);
-        OFX_REQUIRE((r.total >> 6) < (1L << 26) && r.wps >= 2 && r.wps <= 64 && r.wb1 >= 2 && r.wb1 <= 64, OFX_EINVAL);   // reciprocal divisions exact in this range
         OfxProfScope prof("corr_pyramid_pool", s);
         hipLaunchKernelGGL(pyramid_pool_reg_kernel, dim3((unsigned)std::min<long>((r.total + 255) / 256, 256L * 64)), dim3(256), 0, s, r);
         return ofx_launch_status();

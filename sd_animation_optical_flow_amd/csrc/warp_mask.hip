@@ -763,6 +763,15 @@ __global__ __launch_bounds__(256) void travel_distance_kernel(const float* __res
     }
 }
 
+// |flow| of a bare flow field (the RAFT-variant of_calc, reference ofgen.py:45-49): mul, mul, add in f32 (contraction is off for this
+// file), square root through f64 = the correctly rounded f32 result, like np.sqrt
+__global__ __launch_bounds__(256) void flow_magnitude_kernel(const float* __restrict__ flow, float* __restrict__ out, long total) {
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const float2 f = reinterpret_cast<const float2*>(flow)[idx];
+        out[idx] = (float)sqrt((double)(f.x * f.x + f.y * f.y));
+    }
+}
+
 template <int MODE>
 __global__ __launch_bounds__(256) void travel_mask_kernel(const float* __restrict__ conf, const float* __restrict__ flow,
                                                           const float* __restrict__ dist, const float* __restrict__ tin,
@@ -907,6 +916,15 @@ int ofx_travel_distance(const float* flow, const float* conf, float* out, int B,
     hipStream_t s = (hipStream_t)stream;
     OfxProfScope prof("travel_distance", s);
     hipLaunchKernelGGL(travel_distance_kernel, dim3(grid_for(total)), dim3(256), 0, s, flow, conf, out, H, W, total, conf_floor);
+    return ofx_launch_status();
+}
+
+int ofx_flow_magnitude(const float* flow, float* out, long n, void* stream) {
+    OFX_REQUIRE(flow && out && n > 0, OFX_EINVAL);
+    OFX_REQUIRE((((uintptr_t)flow) & 7u) == 0, OFX_EALIGN);
+    hipStream_t s = (hipStream_t)stream;
+    OfxProfScope prof("flow_magnitude", s);
+    hipLaunchKernelGGL(flow_magnitude_kernel, dim3(grid_for(n)), dim3(256), 0, s, flow, out, n);
     return ofx_launch_status();
 }
 

@@ -19,9 +19,10 @@ runs everything inline, which is also what CPU-device test pipelines get for the
 from __future__ import annotations
 
 import threading
+import time
 from collections import deque
 from concurrent.futures import Future, ThreadPoolExecutor
-from typing import Callable, Deque, List, Optional, Sequence, Tuple
+from typing import Callable, Deque, Dict, List, Optional, Sequence, Tuple
 
 import numpy as np
 import torch
@@ -44,30 +45,44 @@ class FrameLoader:
         self.shape = (H, W, 3)
         self.batch = int(batch)
         self.pool = ThreadPoolExecutor(self.threads, thread_name_prefix="ofx-decode") if self.threads else None
-        self._free: Deque[torch.Tensor] = deque()
+        # two rings of pinned staging buffers: full batches, and single frames (a key-frame request must not pin a whole batch:
+        # 75 MB at 64 x 512x768)
+        self._free: Dict[int, Deque[torch.Tensor]] = {1: deque(), self.batch: deque()}
         self._slots = max(2, int(slots))
-        self._made = 0
+        self._made = {1: 0, self.batch: 0}
         self._copy_stream = torch.cuda.Stream(device=self.device) if self.cuda and self.threads else None
         self._inflight: List[Tuple[torch.Tensor, "torch.cuda.Event"]] = []
 
     def _staging(self, n: int) -> torch.Tensor:
-        """A pinned [batch,H,W,3] buffer from a ring of `slots`: a buffer is reused only after the H2D copy that read it is done."""
+        """A pinned [cap,H,W,3] buffer (cap = 1 for single frames, else `batch`) from a ring of `slots` per size: a buffer is reused
+        only after the H2D copy that read it is done.  A full ring waits for its oldest copy; it grows past `slots` only while every
+        buffer sits in a request that was not fetched yet (the caller asked further ahead than it said it would), and never past
+        4 x `slots` -- beyond that the request / fetch protocol is broken and pinned memory would grow without bound."""
+        cap = 1 if n == 1 and self.batch > 1 else self.batch
+        free = self._free[cap]
         still = []
         for buf, ev in self._inflight:                       # reap the copies that have finished
             if ev.query():
-                self._free.append(buf)
+                self._free[buf.shape[0]].append(buf)
             else:
                 still.append((buf, ev))
         self._inflight = still
-        if not self._free and self._made >= self._slots and self._inflight:
-            buf, ev = self._inflight.pop(0)                  # ring full: wait for the oldest copy
+        while not free and self._made[cap] >= self._slots:
+            k = next((j for j, (b, _) in enumerate(self._inflight) if b.shape[0] == cap), None)
+            if k is None:
+                if self._made[cap] >= 4 * self._slots:
+                    raise RuntimeError(f"FrameLoader: {self._made[cap]} staging buffers of {cap} frame(s) are all held by requests that "
+                                       f"were never fetched (slots={self._slots})")
+                break
+            buf, ev = self._inflight.pop(k)                  # ring full: wait for the oldest copy out of a buffer of this size
             ev.synchronize()
-            self._free.append(buf)
-        if self._free:
-            return self._free.popleft()
-        self._made += 1                                      # (also when every buffer sits in a request not fetched yet)
-        t = torch.empty((max(self.batch, n), *self.shape), dtype=torch.uint8)
-        return t.pin_memory() if self.cuda else t
+            free.append(buf)
+        if free:
+            return free.popleft()
+        self._made[cap] += 1
+        # allocated pinned, not `.pin_memory()`-ed: that is a COPY of the fresh buffer, and a CPU copy of this size runs as an
+        # OpenMP region over every core torch sees (192 spinning threads on the 16-core GPU boxes: 8 of a run's 11 CPU-seconds)
+        return torch.empty((cap, *self.shape), dtype=torch.uint8, pin_memory=self.cuda)
 
     def request(self, ids: Sequence[int]):
         ids = [int(i) for i in ids]
@@ -92,7 +107,7 @@ class FrameLoader:
         n = len(ids)
         if not self.cuda:
             out = buf[:n].clone()
-            self._free.append(buf)
+            self._free[buf.shape[0]].append(buf)
             return out
         cur = torch.cuda.current_stream(self.device)
         with torch.cuda.stream(self._copy_stream):
@@ -109,8 +124,14 @@ class FrameLoader:
 
     def close(self) -> None:
         if self.pool:
-            self.pool.shutdown(wait=True)
+            self.pool.shutdown(wait=True, cancel_futures=True)
             self.pool = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc) -> None:
+        self.close()
 
 
 class FrameWriter:
@@ -124,45 +145,63 @@ class FrameWriter:
         self.pool = ThreadPoolExecutor(self.threads, thread_name_prefix="ofx-encode") if self.threads else None
         self._stream = torch.cuda.Stream(device=self.device) if self.cuda and self.threads else None
         self._sem = threading.Semaphore(max(2, int(slots)))
-        self._free: Deque[torch.Tensor] = deque()
+        self._free: Dict[Tuple[int, ...], Deque[torch.Tensor]] = {}      # pinned staging buffers, by frame shape
         self._lock = threading.Lock()
         self._futs: List[Future] = []
 
     def _buffer(self, like: torch.Tensor) -> torch.Tensor:
+        shape = tuple(like.shape)
         with self._lock:
-            if self._free:
-                return self._free.popleft()
-        t = torch.empty(tuple(like.shape), dtype=torch.uint8)
-        return t.pin_memory() if self.cuda else t
+            q = self._free.get(shape)
+            if q:
+                return q.popleft()
+        return torch.empty(shape, dtype=torch.uint8, pin_memory=self.cuda)      # (pinned at birth: `.pin_memory()` would copy)
+
+    def _recycle(self, buf: torch.Tensor) -> None:
+        with self._lock:
+            self._free.setdefault(tuple(buf.shape), deque()).append(buf)
 
     def put(self, index: int, frame: torch.Tensor) -> None:
         if not self.pool:
             self.video.put_ai_frame(int(index), frame.cpu().numpy())
             return
+        if frame.dtype != torch.uint8 or frame.dim() != 3:
+            raise ValueError(f"frame {index}: expected a uint8 [H,W,C] tensor, got {frame.dtype} {tuple(frame.shape)}")
         self._sem.acquire()
-        buf = self._buffer(frame)
-        ev = None
-        if self.cuda and frame.is_cuda:
-            cur = torch.cuda.current_stream(self.device)
-            self._stream.wait_stream(cur)                    # after the kernels that rendered the frame
-            with torch.cuda.stream(self._stream):
-                buf.copy_(frame, non_blocking=True)
-                ev = torch.cuda.Event()
-                ev.record(self._stream)
-            frame.record_stream(self._stream)
-        else:
-            buf.copy_(frame)
+        buf = None
+        try:
+            buf = self._buffer(frame)
+            ev = None
+            if self.cuda and frame.is_cuda:
+                cur = torch.cuda.current_stream(self.device)
+                self._stream.wait_stream(cur)                # after the kernels that rendered the frame
+                with torch.cuda.stream(self._stream):
+                    buf.copy_(frame, non_blocking=True)
+                    ev = torch.cuda.Event()
+                    ev.record(self._stream)
+                frame.record_stream(self._stream)
+            else:
+                buf.copy_(frame)
 
-        def job() -> None:
-            try:
-                if ev is not None:
-                    ev.synchronize()
-                self.video.put_ai_frame(int(index), buf.numpy())
-            finally:
-                with self._lock:
-                    self._free.append(buf)
-                self._sem.release()
-        self._futs.append(self.pool.submit(job))
+            def job() -> None:
+                try:
+                    if ev is not None:
+                        # hipEventSynchronize spins (also for a "blocking" event on this stack: 2.4 of an encoder pool's 3.9
+                        # CPU-seconds per 64 frames were this wait); a sleeping poll gives the core to the decoders
+                        while not ev.query():
+                            time.sleep(0.0005)
+                    self.video.put_ai_frame(int(index), buf.numpy())
+                finally:
+                    self._recycle(buf)
+                    self._sem.release()
+            fut = self.pool.submit(job)
+        except BaseException:
+            # nothing was handed to a worker: give the staging slot (and the buffer, if one was taken) back
+            if buf is not None:
+                self._recycle(buf)
+            self._sem.release()
+            raise
+        self._futs.append(fut)
         if len(self._futs) > 256:                            # keep the list short; failures still surface (result() re-raises)
             done, self._futs = self._futs[:128], self._futs[128:]
             for f in done:

@@ -115,10 +115,7 @@ def of_calc(frame1, frame2, algo, verbose: bool = False):
         if verbose:
             print("v.max()", v.max(), "v.min()", v.min())
         return flow, confidence, v, log_confidence
-    flow = np.asarray(res, np.float32)
-    fl = _dev(flow)[None]
-    ones = torch.ones(fl.shape[:3], dtype=torch.float32, device=fl.device)     # no confidence floor in this variant
-    v = ops.travel_distance(fl, ones, 0.9)[0].cpu().numpy()
+    v = ops.flow_magnitude(_dev(np.asarray(res, np.float32))).cpu().numpy()   # no confidence floor in this variant
     return res, v
 
 

@@ -139,6 +139,16 @@ def travel_distance(flow: torch.Tensor, conf: torch.Tensor, conf_floor: float = 
     return out
 
 
+def flow_magnitude(flow: torch.Tensor) -> torch.Tensor:
+    """|flow| per pixel: f32 [...,2] -> f32 [...] (the RAFT-variant of_calc's `v`, reference ofgen.py:45-49)."""
+    fl = _chk(flow, "flow", torch.float32)
+    if fl.shape[-1] != 2:
+        raise RuntimeError("flow must be [...,2]")
+    out = torch.empty(tuple(fl.shape[:-1]), dtype=torch.float32, device=fl.device)
+    check(_lib.lib().ofx_flow_magnitude(_ptr(fl), _ptr(out), out.numel(), _stream()), "ofx_flow_magnitude")
+    return out
+
+
 def travel_mask(conf, flow, dist, travel, thres: float, warp_mode: str = "cv2_cubic") -> Tuple[torch.Tensor, torch.Tensor]:
     """confidence_to_mask core (before the 15x15 dilation): returns (raw mask, new travel)."""
     c = _chk(conf, "confidence", torch.float32)

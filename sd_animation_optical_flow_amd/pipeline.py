@@ -41,24 +41,71 @@ def _paste_raw(pkt: FramePacket, raw_bgr: torch.Tensor) -> torch.Tensor:
     return ops.merge_images(pkt.warped[None], raw_bgr[None], pkt.mask[None])[0]
 
 
+def default_io_threads(cap: int = 6) -> int:
+    """Decode (and, separately, encode) threads per rank: the cores this process may run on, shared by the ranks of this host
+    (`LOCAL_WORLD_SIZE`, as torchrun sets it) and by the two pools -- min(cap, cores // local ranks // 2), at least 1.  One host
+    with 8 ranks and 128 usable cores gets 6 + 6 per rank; the 16-core single-GPU boxes of this pool get 6 + 6 too; 8 ranks
+    squeezed onto 16 cores get 1 + 1 instead of 96 threads fighting over them."""
+    import os
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        cores = os.cpu_count() or 1
+    try:
+        local = max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1")))
+    except ValueError:
+        local = 1
+    return max(1, min(int(cap), cores // local // 2))
+
+
+def split_edge_batches(units: list, edge: int) -> list:
+    """`units`: a rank's load units in consumption order, `(segment, 'key' | None | [frame ids])`.  The first and the last list
+    of frame ids are cut into a piece of `edge` frames (first: in front; last: behind) and the rest; see `ClipPipeline`."""
+    idx = [i for i, (_, what) in enumerate(units) if isinstance(what, list)]
+    if edge <= 0 or not idx:
+        return units
+    first, last = idx[0], idx[-1]
+    out = []
+    for i, (seg, what) in enumerate(units):
+        pieces = [what]
+        if isinstance(what, list) and len(what) > edge:
+            if i == first and i == last:
+                pieces = [what[:edge], what[edge:-edge], what[-edge:]] if len(what) > 2 * edge else [what[:edge], what[edge:]]
+            elif i == first:
+                pieces = [what[:edge], what[edge:]]
+            elif i == last:
+                pieces = [what[:-edge], what[-edge:]]
+        out += [(seg, p) for p in pieces]
+    return out
+
+
 class ClipPipeline:
     """`algo`: a `pdcnet_of.PDCNetPlus`; `vae`: optional `vae.VaeEncoder`; `render(packet, raw_bgr) -> u8 [H,W,3]` turns a
     packet into the AI frame (default: `_paste_raw`); key frames are rendered by `render_key(raw_bgr) -> u8 [H,W,3]`
     (default: identity).  `batch` frames share one executor call per key frame.  Rank-aware: under an initialised
-    `torch.distributed` group every rank runs the same `run(video)` and takes its share (`packets`).  `io_threads` / `prefetch`: the
-    asynchronous host side (`hostio.FrameLoader` / `FrameWriter`); the output is byte-identical with it off (`io_threads=0`)."""
+    `torch.distributed` group every rank runs the same `run(video)` and takes its share (`packets`) -- `run` and `packets` are
+    COLLECTIVE calls: every rank of `group` must make them, with the same flags.  `io_threads` / `prefetch`: the asynchronous host
+    side (`hostio.FrameLoader` / `FrameWriter`); the output is byte-identical with it off (`io_threads=0`).  `io_threads=None`
+    sizes the pools for the ranks that share this host: `default_io_threads()`.
+    `edge_batch`: the first and the last batch of a rank's share are cut into a piece of `edge_batch` frames and the rest, so that
+    the kernels start after `edge_batch` decoded frames instead of a whole batch and only `edge_batch` frames are left to encode
+    behind the last kernel (a rank whose share is one 64-frame batch -- BASELINE configs[3] -- otherwise pays a batch of decode in
+    front of and a batch of encode behind its 0.6 s of kernels); 0 switches it off.  Part of the plan, not of the host side: it
+    applies with `io_threads=0` too, so the two stay byte-identical."""
 
     def __init__(self, algo, vae=None, render: Optional[Callable] = None, render_key: Optional[Callable] = None, batch: int = 64,
                  warp_mode: str = "bilinear", thres: float = 0.95, ksize: int = 7, mask_blur: float = 4.0, device=None,
-                 io_threads: int = 6, prefetch: int = 2):
+                 io_threads: Optional[int] = None, prefetch: int = 2, edge_batch: int = 16, group=None):
         self.algo, self.vae = algo, vae
         self.render = render or _paste_raw
         self.render_key = render_key or (lambda raw: raw)
         self.batch, self.warp_mode, self.thres, self.ksize, self.mask_blur = int(batch), warp_mode, float(thres), int(ksize), float(mask_blur)
-        self.device = device if device is not None else algo.device
+        self.device = torch.device(device if device is not None else algo.device)
+        self.group = group
         # host side (hostio.py): PNG decode / encode on `io_threads` workers each, `prefetch` batches decoded ahead of the GPU;
         # io_threads = 0 runs all of it inline on the calling thread (the reference's behaviour)
-        self.io_threads, self.prefetch = max(0, int(io_threads)), max(1, int(prefetch))
+        self.io_threads = default_io_threads() if io_threads is None else max(0, int(io_threads))
+        self.prefetch, self.edge_batch = max(1, int(prefetch)), max(0, int(edge_batch))
         # the compute step is the same object bench.py times: with the bilinear warp the AI key frame is warped inside the flow
         # network's convex upsample (one kernel), the cubic modes take upsample -> ofx_warp_and_mask
         self.synth = clip.FrameSynthesizer(algo, warp_mode=warp_mode, thres=self.thres, ksize=self.ksize, bgr=True) if algo is not None else None
@@ -109,6 +156,7 @@ class ClipPipeline:
             units.append((seg, "key" if (owner or mine) else None))
             for b0 in range(0, len(mine), self.batch):
                 units.append((seg, mine[b0:b0 + self.batch]))
+        units = split_edge_batches(units, self.edge_batch)
         loader = hostio.FrameLoader(video, self.device, threads=self.io_threads, slots=self.prefetch + 1, batch=self.batch)
         tickets = {}
 
@@ -136,7 +184,7 @@ class ClipPipeline:
                         key_ai = torch.empty(shape, dtype=torch.uint8, device=self.device)
                     if seg.needs_broadcast:
                         # the one collective of the path; every rank of the group takes part, also those with no frame of this segment
-                        clip.broadcast_keyframe([key_ai], src=seg.owner)
+                        clip.broadcast_keyframe([key_ai], src=seg.owner, group=self.group)
                     continue
                 ids = what
                 raws = loader.fetch(tickets.pop(k))
@@ -145,27 +193,44 @@ class ClipPipeline:
         finally:
             loader.close()
 
+    def _check_collective(self) -> None:
+        """`run` / `shared_flags` under more than one rank are collective: refuse set-ups that would hang instead of failing."""
+        import torch.distributed as dist
+        backend = dist.get_backend(self.group)
+        if backend == "nccl" and self.device.type != "cuda":
+            raise RuntimeError(f"ClipPipeline on device '{self.device}' under the '{backend}' backend: RCCL broadcasts need the rank's "
+                               "GPU tensors -- construct the pipeline with device='cuda:<local rank>'")
+
     def shared_flags(self, video, th: float = 8.5) -> List[bool]:
         """Key-frame flags every rank agrees on: rank 0 runs the detector and broadcasts its decisions (one byte per frame).  Each
         rank deriving them for itself would repeat the detection world-size times and -- should two ranks ever disagree on one
-        frame (another GPU, driver or library build) -- issue different broadcast sequences and hang without a diagnostic."""
+        frame (another GPU, driver or library build) -- issue different broadcast sequences and hang without a diagnostic.
+        COLLECTIVE: every rank of the group calls it; the other ranks wait in the broadcast while rank 0 detects (4 900 frames/s
+        from host memory, DESIGN.md: a 10-minute collective timeout covers 2.9 M frames -- pass explicit `flags` to `run`, or a
+        group created with a longer timeout, for anything beyond that)."""
         rank, world = clip.dist_info()
         if world == 1:
             return self.key_frame_flags(video, th)
         import torch.distributed as dist
+        self._check_collective()
         n = video.num_frames
         t = torch.zeros((n,), dtype=torch.uint8, device=self.device)
         if rank == 0:
             t.copy_(torch.tensor(self.key_frame_flags(video, th), dtype=torch.uint8))
-        dist.broadcast(t, src=0)
+        dist.broadcast(t, src=0, group=self.group)
         return [bool(v) for v in t.cpu().tolist()]
 
     def run(self, video, flags: Optional[List[bool]] = None) -> List[int]:
         """Processes this rank's share of the workspace (all of it in one process); writes `ai-frames/{n:05d}.png` for the frames
         it owns -- results stay with the owning rank; returns the key-frame indices this rank rendered.  Rendered frames leave
         through `hostio.FrameWriter`: D2H into pinned memory on a side stream, PNG encoding on worker threads, one `flush()` at
-        the end (every file is on disk when `run` returns)."""
+        the end (every file is on disk when `run` returns).
+        COLLECTIVE under `torch.distributed`: every rank of the group calls `run` on the same workspace (with `flags=None` the
+        first thing it does is the broadcast of `shared_flags`); a rank that stays away leaves the others waiting for the
+        group's collective timeout."""
         from . import hostio
+        if clip.dist_info()[1] > 1:
+            self._check_collective()
         flags = flags if flags is not None else self.shared_flags(video)
         # staging slots for three batches: `put` must never wait for an encoder while the next batch's kernels are still to be enqueued
         writer = hostio.FrameWriter(video, self.device, threads=self.io_threads, slots=3 * self.batch)
@@ -176,6 +241,11 @@ class ClipPipeline:
                     keys.append(idx)
                     continue
                 writer.put(idx, self.render(pkt, raw))
-        finally:
-            writer.close()                                   # flush: joins the encoders, re-raises their first failure
+        except BaseException:
+            try:
+                writer.close()                               # stop the encoders; what they have to say must not replace the failure above
+            except Exception:
+                pass
+            raise
+        writer.close()                                       # flush: joins the encoders, re-raises their first failure
         return keys

@@ -157,8 +157,9 @@ class _StubPipeline:
     key frame): the rank logic, the workspace I/O and the broadcast are the real ones."""
 
     @staticmethod
-    def make(device="cpu"):
+    def make(device="cpu", flags=None, batch=3, edge_batch=16):
         from sd_animation_optical_flow_amd import pipeline
+        rank0_flags = list(_FLAGS if flags is None else flags)
 
         class P(pipeline.ClipPipeline):
             def process_batch(self, key_raw, key_ai, raws, ids, key_index):
@@ -173,9 +174,10 @@ class _StubPipeline:
                 # (a rank acting on its own list here would plan other segments and the run would hang or write wrong frames)
                 from sd_animation_optical_flow_amd import clip
                 rank, _ = clip.dist_info()
-                return list(_FLAGS) if rank == 0 else [True] + [False] * (video.num_frames - 1)
+                return list(rank0_flags) if rank == 0 else [True] + [False] * (video.num_frames - 1)
         render = lambda pkt, raw: torch.where(pkt.mask[..., None] > 0, raw, pkt.warped)
-        return P(algo=None, render=render, render_key=lambda raw: 255 - raw, batch=3, device=torch.device(device))
+        return P(algo=None, render=render, render_key=lambda raw: 255 - raw, batch=batch, device=torch.device(device),
+                 edge_batch=edge_batch, io_threads=2)
 
 
 def _make_workspace(path, n=23, H=16, W=24):
@@ -225,3 +227,92 @@ def test_two_rank_gloo_pipeline_over_a_workspace(tmp_path):
     for i in range(len(_FLAGS)):
         assert b.generated(i), i
         assert np.array_equal(a.get_ai_frame(i), b.get_ai_frame(i)), i
+
+
+# ------------------------------------------------------------------------------------------------
+# round 5: the broadcast ordering of `ClipPipeline.packets` with EIGHT processes (BASELINE configs[3]'s world size), uneven plans,
+# several cut segments, ranks that hold no frame of a cut segment (they still join its broadcast), ranks with no frame at all and
+# two adjacent key frames.  Every collective carries a timeout: a mis-ordered broadcast fails the test instead of hanging it.
+# ------------------------------------------------------------------------------------------------
+def _flags_of(lengths):
+    f = []
+    for n in lengths:
+        f += [True] + [False] * n
+    return f
+
+
+_FLAGS8_A = _flags_of([21, 0, 13, 1, 1])      # 41 frames, 36 to warp: target 5 per rank -> the 21- and the 13-frame segments are cut
+_FLAGS8_B = _flags_of([3, 0, 2])              # 8 frames, 5 to warp on 8 ranks: both segments cut one frame per rank, three ranks idle
+
+
+def _pipeline8_worker(rank, world, port, ws_a, ws_b):
+    import datetime
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=90))
+    try:
+        from sd_animation_optical_flow_amd.workspace import VideoData
+        va = VideoData(None, (24, 16), ws_a)
+        # flags=None: rank 0's detector decisions reach every rank through `shared_flags`' broadcast; edge_batch=1 cuts the first and
+        # the last batch of every rank's share
+        keys_a = _StubPipeline.make(flags=_FLAGS8_A, batch=2, edge_batch=1).run(va)
+        vb = VideoData(None, (24, 16), ws_b)
+        keys_b = _StubPipeline.make(batch=2, edge_batch=1).run(vb, list(_FLAGS8_B))     # a second run on the same group: no state left behind
+        torch.save((keys_a, keys_b), os.path.join(ws_a, f"keys_r{rank}.pt"))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_eight_rank_gloo_pipeline_with_cut_segments_and_idle_ranks(tmp_path):
+    import numpy as np
+    from sd_animation_optical_flow_amd.workspace import VideoData
+    world = 8
+    plan_a, plan_b = clip.plan_segments(_FLAGS8_A, world), clip.plan_segments(_FLAGS8_B, world)
+    assert sum(p.needs_broadcast for p in plan_a) >= 2 and sum(p.needs_broadcast for p in plan_b) == 2       # >= 2 cut segments each
+    assert any(not p.frames[r] for p in plan_a if p.needs_broadcast for r in range(world))                  # bystanders of a broadcast
+    assert sum(1 for r in range(world) if not any(p.frames[r] for p in plan_b)) == 3                        # ranks with no frame at all
+    assert any(not any(p.frames) for p in plan_a)                                                           # a key frame nobody warps from
+    one_a, _ = _make_workspace(str(tmp_path / "one_a"), n=len(_FLAGS8_A))
+    one_b, _ = _make_workspace(str(tmp_path / "one_b"), n=len(_FLAGS8_B))
+    k1a = _StubPipeline.make(batch=2, edge_batch=1).run(one_a, list(_FLAGS8_A))
+    k1b = _StubPipeline.make(batch=2, edge_batch=1).run(one_b, list(_FLAGS8_B))
+    _make_workspace(str(tmp_path / "a"), n=len(_FLAGS8_A))
+    _make_workspace(str(tmp_path / "b"), n=len(_FLAGS8_B))
+    mp.spawn(_pipeline8_worker, args=(world, _free_port(), str(tmp_path / "a"), str(tmp_path / "b")), nprocs=world, join=True)
+    keys = [torch.load(tmp_path / "a" / f"keys_r{r}.pt") for r in range(world)]
+    for which, plan, k1 in ((0, plan_a, k1a), (1, plan_b, k1b)):
+        got = [k[which] for k in keys]
+        assert sorted(sum(got, [])) == k1                                             # each key frame rendered by exactly one rank ...
+        for r in range(world):
+            assert got[r] == [p.key for p in plan if p.owner == r]                    # ... the one the plan names
+    for single, multi, n in (("one_a", "a", len(_FLAGS8_A)), ("one_b", "b", len(_FLAGS8_B))):
+        x, y = VideoData(None, (24, 16), str(tmp_path / single)), VideoData(None, (24, 16), str(tmp_path / multi))
+        for i in range(n):
+            assert y.generated(i), (multi, i)
+            assert np.array_equal(x.get_ai_frame(i), y.get_ai_frame(i)), (multi, i)   # byte-identical to the single-process run
+
+
+def test_edge_batches_and_io_thread_default(monkeypatch):
+    from sd_animation_optical_flow_amd import pipeline
+    sizes = lambda units: [w if not isinstance(w, list) else len(w) for _, w in units]
+    one = [("s", "key"), ("s", list(range(64)))]                                     # configs[3]: a rank whose share is ONE 64-frame batch
+    assert sizes(pipeline.split_edge_batches(one, 16)) == ["key", 16, 32, 16]
+    assert sizes(pipeline.split_edge_batches(one, 0)) == ["key", 64]
+    assert sizes(pipeline.split_edge_batches([("s", "key"), ("s", list(range(20)))], 16)) == ["key", 16, 4]
+    many = [("s", "key"), ("s", list(range(64))), ("s", list(range(64, 128))), ("t", None), ("t", list(range(200, 240)))]
+    cut = pipeline.split_edge_batches(many, 16)
+    assert sizes(cut) == ["key", 16, 48, 64, None, 24, 16]
+    assert [t for _, w in cut if isinstance(w, list) for t in w] == [t for _, w in many if isinstance(w, list) for t in w]   # order kept
+    assert pipeline.split_edge_batches([("s", None)], 16) == [("s", None)]
+    # pools sized for the ranks that share the host: min(6, cores // local ranks // 2), at least one
+    monkeypatch.setattr(os, "sched_getaffinity", lambda pid: set(range(128)), raising=False)
+    monkeypatch.setenv("LOCAL_WORLD_SIZE", "8")
+    assert pipeline.default_io_threads() == 6
+    monkeypatch.setattr(os, "sched_getaffinity", lambda pid: set(range(16)), raising=False)
+    assert pipeline.default_io_threads() == 1
+    monkeypatch.setenv("LOCAL_WORLD_SIZE", "1")
+    assert pipeline.default_io_threads() == 6
+    monkeypatch.setenv("LOCAL_WORLD_SIZE", "2")
+    assert pipeline.default_io_threads() == 4

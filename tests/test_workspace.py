@@ -111,6 +111,17 @@ def test_frame_loader_prefetches_batches_in_any_order(tmp_path):
             with pytest.raises(Exception):
                 loader.fetch(bad)
         loader.close()
+    # a key-frame request takes a one-frame staging buffer, not a whole batch; the ring is bounded (4 x slots un-fetched requests)
+    with hostio.FrameLoader(video, "cpu", threads=2, slots=2, batch=4) as loader:
+        t1 = loader.request([5])
+        assert t1[2].shape[0] == 1
+        assert np.array_equal(loader.fetch(t1).numpy(), frames[5][None])
+        held = [loader.request([0, 1]) for _ in range(8)]
+        with pytest.raises(RuntimeError):
+            loader.request([2, 3])
+        for t in held:
+            loader.fetch(t)
+    assert loader.pool is None                                  # the context manager closed the decode pool
 
 
 def test_frame_writer_writes_every_frame_and_reports_failures(tmp_path):
@@ -123,11 +134,30 @@ def test_frame_writer_writes_every_frame_and_reports_failures(tmp_path):
             w.put(i, torch.from_numpy(255 - f))
         w.close()
         assert all(np.array_equal(video.get_ai_frame(i), 255 - f) for i, f in enumerate(frames))
-    w = hostio.FrameWriter(video, "cpu", threads=2)
+    w = hostio.FrameWriter(video, "cpu", threads=2, slots=2)
     w.put(0, torch.from_numpy(frames[0]))
-    w.put(1, torch.zeros((12, 20), dtype=torch.uint8))          # not a [H,W,3] frame: the encoder thread raises ...
     with pytest.raises(ValueError):
-        w.close()                                               # ... and flush / close re-raises it
+        w.put(1, torch.zeros((12, 20), dtype=torch.uint8))      # not a [H,W,3] frame: refused before a staging slot is taken
+    # frames of another shape get their own staging buffers (never a broadcast into a recycled one) ...
+    for i in range(4):
+        w.put(2 + i, torch.full((12, 20, 3), 10 * i, dtype=torch.uint8))
+    w.flush()
+    w.put(1, torch.full((6, 20, 3), 7, dtype=torch.uint8))
+    w.flush()
+    assert sorted(w._free) == [(6, 20, 3), (12, 20, 3)]
+    # ... a failure on an encoder thread surfaces at flush / close, and its staging slot comes back (no deadlock afterwards)
+    real = video.put_ai_frame
+    def failing(i, frame):
+        if i == 3:
+            raise OSError("disk full")
+        return real(i, frame)
+    video.put_ai_frame = failing
+    for i in (3, 4, 5, 6):                                      # more puts than slots after the failure
+        w.put(i, torch.from_numpy(frames[i]))
+    with pytest.raises(OSError):
+        w.close()
+    video.put_ai_frame = real
+    assert np.array_equal(video.get_ai_frame(6), frames[6])
 
 
 def test_png_writer_round_trips_through_pillow():

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """End-to-end rate of `pipeline.ClipPipeline.run` over a workspace on ONE GPU, with the device-only rate beside it.
 
-    python tools/pipeline_rate.py [frames=256] [io_threads=4]
+    python tools/pipeline_rate.py [frames=256] [io_threads=default_io_threads()]
 
 A 512x768 workspace of `frames` PNGs (the bench clip's frames: 4 key-frame segments) is written to a temporary directory, then
 
@@ -12,7 +12,10 @@ A 512x768 workspace of `frames` PNGs (the bench clip's frames: 4 key-frame segme
   device_only    the same `process_batch` + render calls on frames already resident in HBM, nothing written.
 
 SURVEY 8(e) names input decode / H2D per rank as the limit of the 8-GPU scaling; `ratio` = end_to_end / device_only is the share of
-the device rate the host side sustains (target >= 0.85), `cores` the host cores this process may use.
+the device rate the host side sustains (target >= 0.85), `cores` the host cores this process may use.  `host_cpu_s_per_frame` is
+the process's CPU time (every thread: decode, encode, the enqueueing thread) per frame of the end-to-end run, and
+`cores_for_8_ranks` = 8 ranks x that rank's frames/s x CPU-seconds per frame: the host cores one 8-GPU node needs for all of its
+ranks to sustain this rate (no 8-GPU node was reachable from the build sessions: a projection, not a measurement).
 """
 import json
 import os
@@ -28,12 +31,15 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
-def measure(n_frames: int = 256, io_threads: int = 4, seg: int = 64, batch: int = 64, keep: bool = False) -> dict:
+def measure(n_frames: int = 256, io_threads=None, seg: int = 64, batch: int = 64, keep: bool = False, reps: int = 2, inline: bool = True,
+            edge_batch: int = 16) -> dict:
     import bench
     from sd_animation_optical_flow_amd import pdcnet_of, pipeline
     from sd_animation_optical_flow_amd.workspace import VideoData
     dev = torch.device("cuda")
     H, W = bench.H, bench.W
+    if io_threads is None:
+        io_threads = pipeline.default_io_threads()
     n_seg = max(1, n_frames // seg)
     frames, key, _, _ = bench.make_clip(seg - 1, H, W, dev)
     clip_frames = []
@@ -52,19 +58,22 @@ def measure(n_frames: int = 256, io_threads: int = 4, seg: int = 64, batch: int 
         algo = pdcnet_of.PDCNetPlus("random:0", device=dev)
 
         def run(threads):
-            pipe = pipeline.ClipPipeline(algo, batch=batch, warp_mode="bilinear", thres=0.95, ksize=7, io_threads=threads)
+            pipe = pipeline.ClipPipeline(algo, batch=batch, warp_mode="bilinear", thres=0.95, ksize=7, io_threads=threads,
+                                         edge_batch=edge_batch)
             shutil.rmtree(os.path.join(root, "ai-frames"))
             os.makedirs(os.path.join(root, "ai-frames"))
             torch.cuda.synchronize()
+            c = time.process_time()
             t = time.perf_counter()
             pipe.run(video, flags)
             torch.cuda.synchronize()
             dt = time.perf_counter() - t
+            cpu = time.process_time() - c
             assert all(video.generated(i) for i in range(n))
-            return n / dt
+            return n / dt, cpu / n
 
         # device only: the same compute calls over resident frames
-        pipe = pipeline.ClipPipeline(algo, batch=batch, warp_mode="bilinear", thres=0.95, ksize=7, io_threads=0)
+        pipe = pipeline.ClipPipeline(algo, batch=batch, warp_mode="bilinear", thres=0.95, ksize=7, io_threads=0, edge_batch=0)
         dev_frames = torch.from_numpy(__import__("numpy").stack(clip_frames)).to(dev)
 
         def device_only():
@@ -83,15 +92,20 @@ def measure(n_frames: int = 256, io_threads: int = 4, seg: int = 64, batch: int 
             return n / (time.perf_counter() - t)
 
         device_only()                                         # warm-up: workspaces, kernels
-        d = max(device_only(), device_only())
+        d = max(device_only() for _ in range(max(1, reps)))
         run(io_threads)                                       # warm-up: thread pools, pinned buffers, page cache
-        e = max(run(io_threads), run(io_threads))
-        i0 = run(0)
-        return {"workload": f"{n}-frame 512x768 workspace, {n_seg} key-frame segments, ClipPipeline.run (flow both ways + forward-backward "
-                            f"confidence, warp + mask, SD-inpaint inputs, render, PNG in / PNG out), 1 GPU",
-                "frames": n, "png_mb_per_frame": round(png_mb, 3), "io_threads": io_threads, "cores": bench.usable_cores(),
-                "end_to_end_fps": round(e, 2), "inline_io_fps": round(i0, 2), "device_only_fps": round(d, 2),
-                "ratio": round(e / d, 4), "inline_ratio": round(i0 / d, 4), "extract_s": round(t_extract, 2)}
+        e, cpu_s = max(run(io_threads) for _ in range(max(1, reps)))
+        out = {"workload": f"{n}-frame 512x768 workspace, {n_seg} key-frame segments, ClipPipeline.run (flow both ways + forward-backward "
+                           f"confidence, warp + mask, SD-inpaint inputs, render, PNG in / PNG out), 1 GPU",
+               "frames": n, "png_mb_per_frame": round(png_mb, 3), "io_threads": io_threads, "edge_batch": edge_batch,
+               "cores": bench.usable_cores(),
+               "end_to_end_fps": round(e, 2), "device_only_fps": round(d, 2), "ratio": round(e / d, 4),
+               "host_cpu_s_per_frame": round(cpu_s, 5), "cores_for_8_ranks": round(8 * e * cpu_s, 1), "extract_s": round(t_extract, 2)}
+        if inline:
+            i0, _ = run(0)
+            out["inline_io_fps"] = round(i0, 2)
+            out["inline_ratio"] = round(i0 / d, 4)
+        return out
     finally:
         if not keep:
             shutil.rmtree(root, ignore_errors=True)
@@ -99,5 +113,6 @@ def measure(n_frames: int = 256, io_threads: int = 4, seg: int = 64, batch: int 
 
 if __name__ == "__main__":
     nf = int(sys.argv[1]) if len(sys.argv) > 1 else 256
-    th = int(sys.argv[2]) if len(sys.argv) > 2 else 4
-    print(json.dumps(measure(nf, th)))
+    th = int(sys.argv[2]) if len(sys.argv) > 2 else None
+    eb = int(sys.argv[3]) if len(sys.argv) > 3 else 16
+    print(json.dumps(measure(nf, th, edge_batch=eb)))
