@@ -44,6 +44,30 @@ def kernel_stats(db):
         print(f"{n:<112} {gx:>8} {gy:>4} {s[0]:>6} {s[1] / 1e6:>10.3f} {s[1] / s[0] / 1e3:>10.2f}")
 
 
+def gap_stats(db):
+    """Idle time between consecutive dispatches of the same queue (= HIP stream): what the kernel boundaries of a latency-bound
+    workload cost, as opposed to the kernels themselves.  Printed under the --stats tables when the trace has start / end columns."""
+    c = sqlite3.connect(db)
+    cols = [r[1] for r in c.execute("pragma table_info('kernels')")]
+    if not {"start", "end"} <= set(cols):
+        print("\n# (no start / end columns in this trace: columns are", cols, ")")
+        return
+    qcol = "queue_id" if "queue_id" in cols else ("stream_id" if "stream_id" in cols else None)
+    rows = c.execute(f"select {qcol or '0'}, start, end, name from kernels order by start").fetchall()
+    byq = {}
+    for q, st, en, name in rows:
+        byq.setdefault(q, []).append((st, en, short(name)))
+    print("\n# gaps between consecutive dispatches of one queue (ns -> us); gaps > 200 us (host-side pauses between calls) excluded")
+    print(f"{'queue':>8} {'dispatches':>10} {'busy_ms':>10} {'gaps':>8} {'gap_sum_ms':>11} {'median_us':>10} {'p90_us':>8} {'span_ms':>9}")
+    for q, ev in sorted(byq.items(), key=lambda kv: -len(kv[1])):
+        gaps = sorted((ev[i + 1][0] - ev[i][1]) / 1e3 for i in range(len(ev) - 1) if 0 <= ev[i + 1][0] - ev[i][1] < 200e3)
+        busy = sum(e - s_ for s_, e, _ in ev) / 1e6
+        if not gaps:
+            continue
+        print(f"{str(q):>8} {len(ev):>10} {busy:>10.3f} {len(gaps):>8} {sum(gaps) / 1e3:>11.3f} {gaps[len(gaps) // 2]:>10.2f} "
+              f"{gaps[int(len(gaps) * 0.9)]:>8.2f} {(ev[-1][1] - ev[0][0]) / 1e6:>9.3f}")
+
+
 def pmc_stats(db):
     c = sqlite3.connect(db)
     cols = [r[1] for r in c.execute("pragma table_info('counters_collection')")]
@@ -60,3 +84,4 @@ if __name__ == "__main__":
         pmc_stats(sys.argv[2])
     else:
         kernel_stats(sys.argv[1])
+        gap_stats(sys.argv[1])
