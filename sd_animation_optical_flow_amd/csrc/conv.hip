@@ -1218,16 +1218,6 @@ int ofx_conv2d_volpool(const ofx_conv_desc* d, float alpha, float* pool_out, lon
     OFX_REQUIRE(d->epi == OFX_EPI_PLAIN && d->act == OFX_ACT_NONE && !d->res && !d->addend && !d->nmean &&
                     !d->scale && !d->shift && d->Cout % 128 == 0 && d->tile == 0,
                 OFX_EINVAL);
-    // exact fp32, a plain [N x K] x [Nb x K]^T product: the dedicated persistent kernel (vol_gemm.hip).  OFX_VOL_GENERIC=1 keeps
-    // the round-4 path (this kernel family's batched mode) for A/B runs; the split-bf16 arithmetics still take it
-    static const bool generic = getenv("OFX_VOL_GENERIC") != nullptr;
-    if (!generic && d->precision == OFX_PREC_FP32 && !d->in1 && d->KH == 1 && d->KW == 1 && d->stride == 1 && d->padH == 0 && d->padW == 0 &&
-        d->B == 1 && d->ld0 == d->c0 && d->ldo == d->Cout && d->Hin == d->Hout && d->Win == d->Wout) {
-        const int nzv = d->nz > 1 ? d->nz : 1;
-        const int stv = ofx_vol_gemm_launch(d->in0, nzv > 1 ? d->a_zs : 0, d->w, nzv > 1 ? d->w_zs : 0, d->out, nzv > 1 ? d->o_zs : 0, pool_out,
-                                            nzv > 1 ? pool_zs : 0, d->Hout * d->Wout, d->Cout, d->c0, nzv, wb0, wb1, slice1, alpha, (hipStream_t)stream);
-        if (stv != OFX_EINVAL) return stv;
-    }
     tl_pool.on = true; tl_pool.out = pool_out; tl_pool.zs = pool_zs; tl_pool.wb0 = wb0; tl_pool.wb1 = wb1; tl_pool.slice1 = slice1;
     const int st = ofx_conv2d_alpha(d, alpha, stream);
     tl_pool = VolPool{};

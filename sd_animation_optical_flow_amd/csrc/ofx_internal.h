@@ -42,11 +42,6 @@ extern "C" int ofx_conv2d_alpha(const ofx_conv_desc* d, float alpha, void* strea
 // conv.hip: the blocked correlation volume GEMM that also writes pyramid level 1 from its accumulators
 int ofx_conv2d_volpool(const ofx_conv_desc* d, float alpha, float* pool_out, long pool_zs, int wb0, int wb1, int slice1, void* stream);
 
-// vol_gemm.hip: the correlation volume as a dedicated persistent batched GEMM (exact fp32; level 1 of the pyramid from the
-// accumulators when `pool` is given).  OFX_EINVAL = shape not taken, run the generic GEMM of conv.hip
-int ofx_vol_gemm_launch(const float* A, long a_zs, const float* Bm, long b_zs, float* out, long o_zs, float* pool, long pool_zs, int N, int Nb,
-                        int K, int nz, int wb0, int wb1, int slice1, float alpha, hipStream_t s);
-
 // conv.hip / net_misc.hip: instance-norm statistics out of the convolution epilogue (rows_per_image = 0: not produced, use
 // ofx_inorm_stats) and their per-image reduction
 int ofx_conv2d_stats(const ofx_conv_desc* d, float* part, size_t part_floats, int* rows_per_image, void* stream);

@@ -24,6 +24,7 @@
 
 #include <algorithm>
 #include <cstdlib>
+#include <cstring>
 #include <type_traits>
 
 namespace {
@@ -37,8 +38,9 @@ struct VolK {
     int mtiles, ntiles, group_m;
     int wb0, wb1, slice1;
     float alpha;
-    long total;                         // tiles of the launch
+    int total;                          // tiles of the launch
     int wgs;                            // resident workgroups (grid size), a multiple of 8
+    int stagger, stagger_mode;          // start-phase probe: workgroup phase x `stagger` x 64 cycles of s_sleep before the first load
 };
 
 constexpr int BM = 128, BN = 128, BK = 16, LDK = BK + 4;
@@ -60,18 +62,22 @@ __global__ __launch_bounds__(256, 4) void vol_gemm_kernel(const VolK p) {
     // this workgroup's tiles: XCD x (= block id mod 8, where the hardware puts the block) owns the contiguous range
     // [x0, x0 + cnt) of the global order; its workgroups take local indices slot, slot + per_xcd, ...
     const int xcd = (int)(blockIdx.x & 7), slot = (int)(blockIdx.x >> 3), per_xcd = p.wgs >> 3;
-    const long q8 = p.total >> 3, r8 = p.total & 7;
-    const long x0 = xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;
-    const long cnt = q8 + (xcd < r8 ? 1 : 0);
-    const long mine = slot < cnt ? (cnt - slot + per_xcd - 1) / per_xcd : 0;     // tiles of this workgroup
+    const int q8 = p.total >> 3, r8 = p.total & 7;
+    const int x0 = xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;
+    const int cnt = q8 + (xcd < r8 ? 1 : 0);
+    const int mine = slot < cnt ? (cnt - slot + per_xcd - 1) / per_xcd : 0;      // tiles of this workgroup
     if (mine == 0) return;
     const int NK = p.K / BK;
-    const long per_z = (long)p.mtiles * p.ntiles;
+    const int per_z = p.mtiles * p.ntiles;
+    if (p.stagger > 0) {
+        const int ph = p.stagger_mode == 0 ? (slot >> 5) & 3 : p.stagger_mode == 1 ? slot & 3 : (slot >> 3) & 3;
+        for (int i = 0; i < ph * p.stagger; ++i) __builtin_amdgcn_s_sleep(64);
+    }
 
-    auto decode = [&](long i, int& z, int& mt, int& nt) {                          // i-th tile of this workgroup
-        const long L = x0 + slot + i * per_xcd;
-        z = (int)(L / per_z);
-        const int rem = (int)(L - (long)z * per_z);
+    auto decode = [&](int i, int& z, int& mt, int& nt) {                           // i-th tile of this workgroup
+        const int L = x0 + slot + i * per_xcd;
+        z = L / per_z;
+        const int rem = L - z * per_z;
         const int per = p.group_m * p.ntiles;
         const int g = rem / per, rr = rem - g * per;
         const int gm = min(p.group_m, p.mtiles - g * p.group_m);                  // the last group may be short
@@ -80,7 +86,7 @@ __global__ __launch_bounds__(256, 4) void vol_gemm_kernel(const VolK p) {
     };
 
     // ---- issue side: the tile whose chunks are being LOADED (up to two chunks ahead of the one being multiplied)
-    long it = 0;                         // tile index (of this workgroup) on the issue side
+    int it = 0;                          // tile index (of this workgroup) on the issue side
     int ik = 0;                          // its next chunk
     __amdgpu_buffer_rsrc_t rsA, rsB;
     int voa0, voa1, vob0, vob1;
@@ -132,7 +138,7 @@ __global__ __launch_bounds__(256, 4) void vol_gemm_kernel(const VolK p) {
     // ---- epilogue of the tile on the compute side.  C/D layout of the 32x32 MFMA: column = lane & 31, row = (e & 3) + 8 (e >> 2)
     // + 4 (lane >> 5).  Stores only (no LDS: the next tile's first chunk already sits there), through descriptors based at the
     // tile's first row, so offsets stay small whatever the size of the volume.
-    auto epilogue = [&](long ct) __attribute__((always_inline)) {
+    auto epilogue = [&](int ct) __attribute__((always_inline)) {
         int z, mt, nt;
         decode(ct, z, mt, nt);
         const int m0 = mt * BM, n0 = nt * BN;
@@ -191,7 +197,7 @@ __global__ __launch_bounds__(256, 4) void vol_gemm_kernel(const VolK p) {
     // ---- one pipeline over every chunk of every tile of this workgroup, one barrier per chunk:
     //   MFMA block on stage[g & 1] -> commit chunk g + 1 to the other stage -> barrier -> issue chunk g + 2
     int g = 0;
-    for (long ct = 0; ct < mine; ++ct) {
+    for (int ct = 0; ct < mine; ++ct) {
         for (int kt = 0; kt < NK; ++kt, ++g) {
             const float* As = smem + (g & 1) * STAGE;
             const float* Bs = As + BM * LDK;
@@ -261,11 +267,15 @@ int ofx_vol_gemm_launch(const float* A, long a_zs, const float* Bm, long b_zs, f
     k.group_m = k.ntiles >= 8 ? 8 : 1;
     k.wb0 = wb0; k.wb1 = wb1; k.slice1 = slice1;
     k.alpha = alpha;
-    k.total = (long)k.mtiles * k.ntiles * nz;
+    const long total = (long)k.mtiles * k.ntiles * nz;
+    OFX_REQUIRE(total < (1L << 30), OFX_EINVAL);
+    k.total = (int)total;
+    static const char* st_env = getenv("OFX_VOL_STAGGER");                  // probe: "<units of 64x64 cycles>[,mode]"
+    if (st_env) { k.stagger = atoi(st_env); const char* c = strchr(st_env, ','); k.stagger_mode = c ? atoi(c + 1) : 0; }
     const int res = resident_wgs();
     OFX_REQUIRE(res >= 8, OFX_EINVAL);
     // fewer tiles than resident workgroups: one tile each (the grid stays a multiple of 8 so that every XCD gets its range)
-    k.wgs = (int)std::min<long>(res, ((k.total + 7) / 8) * 8);
+    k.wgs = (int)std::min<long>(res, ((total + 7) / 8) * 8);
     OfxProfScope prof("igemm_corr_volume", s);
     prof.flops(2.0 * (double)N * Nb * K * nz);
     if (pool) hipLaunchKernelGGL(vol_gemm_kernel<true>, dim3((unsigned)k.wgs), dim3(256), 0, s, k);
