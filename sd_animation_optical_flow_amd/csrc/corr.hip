@@ -293,6 +293,7 @@ struct LookupBArgs {
     const float* coords;
     float* out;
     int ldo;
+    int pad;                                // zeros written behind the 324 features of a row (0 ... 47): convc1's whole chunks
     long M;
 };
 
@@ -395,7 +396,9 @@ __global__ __launch_bounds__(256) void corr_lookup_blocked_kernel(const LookupBA
                     acc = acc + v01 * w01[l];
                     acc = acc + v10 * w10[l];
                     acc = acc + v11 * w11[l];
-                    if (rr == 0 || lane < rd * rd - 64) o[l * (rd * rd) + rr * 64 + lane] = acc;
+                    // (the last round of the last level also writes the row's zero padding: ldo - 324 floats, convc1's whole chunks)
+                    const int live = rd * rd - 64 + (l == 3 ? a.pad : 0);
+                    if (rr == 0 || lane < live) o[l * (rd * rd) + rr * 64 + lane] = (rr == 0 || lane < rd * rd - 64) ? acc : 0.0f;
                 }
             }
             __builtin_amdgcn_wave_barrier();                   // the window is rewritten next
@@ -706,7 +709,17 @@ int ofx_corr_volume(const float* f1, const float* f2, float* const* pyr, int B, 
 
 int ofx_corr_lookup(const float* const* pyr, const float* coords, float* out, int ldo, int B, int h, int w,
                     int levels, int radius, void* stream) {
+    return ofx_corr_lookup_pad(pyr, coords, out, ldo, 0, B, h, w, levels, radius, stream);
+}
+
+}  // extern "C"
+
+// internal (the RAFT executor): the same lookup that also writes `pad` zeros behind the features of every row -- the executor keeps
+// rows of 336 floats so that convc1 walks whole 16-wide chunks
+int ofx_corr_lookup_pad(const float* const* pyr, const float* coords, float* out, int ldo, int pad, int B, int h, int w,
+                        int levels, int radius, void* stream) {
     OFX_REQUIRE(pyr && coords && out && B > 0 && h > 0 && w > 0, OFX_EINVAL);
+    OFX_REQUIRE(pad >= 0 && pad <= 47 && (pad == 0 || (levels == 4 && radius == 4)) && ldo >= levels * (2 * radius + 1) * (2 * radius + 1) + pad, OFX_EINVAL);
     OFX_REQUIRE(levels >= 1 && levels <= kMaxLevels && radius >= 0 && 2 * radius + 2 <= kMaxWin, OFX_EINVAL);
     OFX_REQUIRE(ldo >= levels * (2 * radius + 1) * (2 * radius + 1), OFX_EINVAL);
     OFX_REQUIRE((((uintptr_t)coords) & 7u) == 0, OFX_EALIGN);
@@ -722,7 +735,7 @@ int ofx_corr_lookup(const float* const* pyr, const float* coords, float* out, in
             a.wb[l] = ((w >> l) + 7) >> 3;
             a.slice[l] = (long)a.hb[l] * a.wb[l] * 32;
         }
-        a.coords = coords; a.out = out; a.ldo = ldo; a.M = M;
+        a.coords = coords; a.out = out; a.ldo = ldo; a.M = M; a.pad = pad;
         // window blocks are read once per iteration out of a 12.8 GB pyramid: non-temporal loads (aux bit 1 on gfx950) keep them from
         // displacing the row the kernel is writing for convc1 (tools/lookup_bench.py: 363 -> 353 us, lookup + convc1 889 -> 875 us)
         hipLaunchKernelGGL(corr_lookup_blocked_kernel<2>, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, s, a);
@@ -736,10 +749,13 @@ int ofx_corr_lookup(const float* const* pyr, const float* coords, float* out, in
         a.wb[l] = ((w >> l) + 7) >> 3;
         a.slice[l] = ofx_corr_slice_floats_l(h >> l, w >> l);
     }
+    OFX_REQUIRE(pad == 0, OFX_EINVAL);
     a.coords = coords; a.out = out; a.ldo = ldo; a.M = M; a.levels = levels; a.r = radius;
     hipLaunchKernelGGL(corr_lookup_generic_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, s, a);
     return ofx_launch_status();
 }
+
+extern "C" {
 
 int ofx_local_corr_fwd(const float* fmap1, const float* fmap2, const float* coords, float* corr, int B, int H1,
                        int W1, int H2, int W2, int C, int N, int r, void* stream) {

@@ -62,6 +62,9 @@ int ofx_local_corr_launch(const float* f1, const float* f2, const float* coords,
                           float cscale, hipStream_t s);
 // blocked pyramid layout (corr.hip): floats per pixel slice of an hl x wl level; fmap rows -> blocked order
 int ofx_corr_slice_floats_l(int hl, int wl);
+// ofx_corr_lookup that also writes `pad` (<= 47; 4 levels, radius 4 only) zeros behind the features of every output row
+int ofx_corr_lookup_pad(const float* const* pyr, const float* coords, float* out, int ldo, int pad, int B, int h, int w, int levels,
+                        int radius, void* stream);
 int ofx_corr_block_rows(const float* src, float* dst, int n, int h, int w, int D, hipStream_t s);
 int ofx_corr_pool_launch(const float* l0, float* l1, float* l2, float* l3, int B, int h, int w, int levels, hipStream_t s,
                          bool from_l1 = false);

@@ -55,6 +55,10 @@ constexpr int HD = 128;      // hidden dim (raft.py:38)
 constexpr int CD = 128;      // context dim (raft.py:39)
 constexpr int FD = 256;      // feature dim (raft.py:54)
 constexpr int LEVELS = 4, RADIUS = 4, CORR_CH = LEVELS * (2 * RADIUS + 1) * (2 * RADIUS + 1);   // 324
+// row of the lookup's output = convc1's operand: 324 correlation features + 12 zeros.  336 = 21 whole 16-wide K chunks, so every
+// chunk of the 1x1 convolution lies inside the row (the scalar-coordinate schedule of conv.hip applies: 116 against 111 TF at the
+// same 21 chunks, tools/experiments/README.md) and rows start on 64-byte boundaries; the lookup writes the zeros itself
+constexpr int CORR_LD = 336;
 // hx row = [h(128) | motion(126) flow(2) | inp(128)] = 384 floats.  The recurrent part (h, motion) is
 // contiguous so the per-iteration GRU convolutions read 256 channels; `inp` (the context features) is
 // loop-invariant: its contribution to the six GRU convolutions (+ their biases) is computed ONCE per
@@ -555,7 +559,7 @@ static RaftWs carve(void* base, size_t cap, int B, int H, int W, int flags, int 
     w.gadd = c.take((size_t)M * GADD_LD);
     w.coords1 = c.take((size_t)M * 2);
     w.frows = c.take((size_t)M * FROW);
-    w.corr = c.take((size_t)M * CORR_CH);
+    w.corr = c.take((size_t)M * CORR_LD);
     w.c1 = c.take((size_t)M * 256);
     w.corflo = c.take((size_t)M * 256);
     w.f1 = c.take((size_t)M * 128);
@@ -589,6 +593,7 @@ static int run_recurrence(ofx_raft* r, const RaftWs& ws, int B, int h, int w, in
         if (G.st) return G.st;
     }
 
+    if (alt) OFX_HIP_CHECK(hipMemsetAsync(ws.corr, 0, (size_t)B * N * CORR_LD * sizeof(float), s));   // (the pad columns: the volume-free kernel writes 324 of 336)
     Launcher L{s};
     L.precision = precision;
     L.sk_ws = ws.sk[0]; L.sk_bytes = ws.sk[0] ? SK_BYTES : 0;
@@ -607,17 +612,17 @@ static int run_recurrence(ofx_raft* r, const RaftWs& ws, int B, int h, int w, in
         if ((L.st = LF.st)) break;
         // correlation features at the current estimate
         if (!alt) {
-            L.st = ofx_corr_lookup(pyr_c, ws.coords1, ws.corr, CORR_CH, B, h, w, LEVELS, RADIUS, s);
+            L.st = ofx_corr_lookup_pad(pyr_c, ws.coords1, ws.corr, CORR_LD, CORR_LD - CORR_CH, B, h, w, LEVELS, RADIUS, s);
         } else {
             for (int l = 0; l < LEVELS && !L.st; ++l) {
                 if (sh1 || sh2) { L.st = OFX_EINVAL; break; }   // alt-corr path: per-pair feature maps only
-                L.st = ofx_local_corr_launch(ws.fmap1, ws.f2l[l], ws.coords1, ws.corr + (long)l * rd2, N * CORR_CH, 0, 1,
-                                             CORR_CH, B, h, w, h >> l, w >> l, FD, 1, RADIUS, 1.0f / std::sqrt((float)FD),
+                L.st = ofx_local_corr_launch(ws.fmap1, ws.f2l[l], ws.coords1, ws.corr + (long)l * rd2, N * CORR_LD, 0, 1,
+                                             CORR_LD, B, h, w, h >> l, w >> l, FD, 1, RADIUS, 1.0f / std::sqrt((float)FD),
                                              1.0f / (float)(1 << l), s);
             }
         }
         // motion encoder (update.py:88-97)
-        L.conv(C("convc1"), ws.corr, CORR_CH, CORR_CH, nullptr, 0, 0, ws.c1, 256, B, h, w, 1, OFX_ACT_RELU);
+        L.conv(C("convc1"), ws.corr, CORR_LD, CORR_LD, nullptr, 0, 0, ws.c1, 256, B, h, w, 1, OFX_ACT_RELU);
         L.conv(C("convc2"), ws.c1, 256, 256, nullptr, 0, 0, ws.corflo, 256, B, h, w, 1, OFX_ACT_RELU);
         if (!L.st) L.st = S.join(0);
         L.conv(C("conv"), ws.corflo, 256, 256, nullptr, 0, 0, ws.hx + MOT_OFF, HX_LD, B, h, w, 1, OFX_ACT_RELU);
@@ -690,7 +695,7 @@ int ofx_raft_create(const ofx_tensor* tensors, int n, ofx_raft** out) {
     if (!st) st = build_encoder(r, sd, "cnet", true);
     if (!st) st = build_encoder(r, sd, "cnet", true, "cnetb");
     const char* ub = "update_block.";
-    if (!st) st = add_conv(r, sd, std::string(ub) + "encoder.convc1", "convc1", 0, "", 1.f);
+    if (!st) st = add_conv(r, sd, std::string(ub) + "encoder.convc1", "convc1", CORR_LD, "", 1.f);   // input rows padded to 336 (zero weights)
     if (!st) st = add_conv(r, sd, std::string(ub) + "encoder.convc2", "convc2", 0, "", 1.f);
     std::vector<float> wf1;   // must outlive add_conv below
     if (!st) {
@@ -891,7 +896,7 @@ static int raft_forward_impl(ofx_raft* r, const uint8_t* image1, const uint8_t* 
     reg("fmap2", ws.fmap2, (size_t)n2 * N * FD);
     reg("hx", ws.hx, (size_t)M * HX_LD);
     reg("coords1", ws.coords1, (size_t)M * 2);
-    reg("corr", ws.corr, (size_t)M * CORR_CH);
+    reg("corr", ws.corr, (size_t)M * CORR_LD);   // rows of 336: 324 features + 12 zeros
     reg("mask", ws.mask, (size_t)M * 576);
     if (!alt)
         for (int l = 0; l < LEVELS; ++l) {
