@@ -18,7 +18,11 @@ Prints ONE JSON line (rank 0) with the driver's contract fields plus
                   upsample, warp, mask) against the 8 TB/s HBM peak,
   "cpu_baseline": the CPU oracle (a port; the reference's Python cannot travel to the GPU box) timed
                   on the host cores on a bounded sample of the same workload,
-  "single_pair":  BASELINE.json configs[1] (one 512x768 pair) latency/throughput.
+  "single_pair":  BASELINE.json configs[1] (one 512x768 pair) latency/throughput,
+  "batch_sweep":  the batches in between (1, 4, 16, 64 frames per call),
+  "workspace_pipeline": the path end to end over a PNG workspace (`pipeline.ClipPipeline.run`: decode -> H2D -> flow both ways ->
+                  warp + mask -> SD-inpaint inputs -> render -> D2H -> encode) against the same calls on resident frames, with the
+                  host CPU-seconds per frame and the one-batch-per-rank share of BASELINE configs[3]; never `value`.
 """
 from __future__ import annotations
 
