@@ -872,14 +872,24 @@ __global__ __launch_bounds__(256 * KS, (BK == 16 && KS == 1) ? (PREC == 3 ? 2 : 
         // the whole L2 back: measured 2x slower end to end).
         __shared__ int sk_last;
         const int tile_id = mt * p.ntiles + nt;
-        float* mine = p.sk_part + ((long)tile_id * p.ksplit + split) * (BM * BN);
+        // partial tiles travel as 16-byte agent-scope (sc1) stores and loads through buffer descriptors: tile layout
+        // [(i, j) sub-tile][e / 4][thread][4 floats] -- one instruction moves 1 KB per wave where the first version's 4-byte atomics
+        // moved 256 B (round 5: 8.57 -> 8.4x ms on one 512x768 pair; same values, same summation order)
+        typedef int v4i_sk __attribute__((ext_vector_type(4)));
+        constexpr int kSc1 = 16;                                   // cache-policy bit sc1 of gfx940+ buffer instructions
+        const __amdgpu_buffer_rsrc_t rs_mine = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)(p.sk_part + ((long)tile_id * p.ksplit + split) * (BM * BN)), (short)0, BM * BN * 4, 0x00020000);
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int j = 0; j < TN; ++j)
 #pragma unroll
-                for (int e = 0; e < 16; ++e)
-                    __hip_atomic_store(mine + ((i * TN + j) * 16 + e) * 256 + tid, acc[i][j][e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                for (int e4 = 0; e4 < 4; ++e4) {
+                    v4i_sk t;
+                    t[0] = __float_as_int(acc[i][j][e4 * 4 + 0]); t[1] = __float_as_int(acc[i][j][e4 * 4 + 1]);
+                    t[2] = __float_as_int(acc[i][j][e4 * 4 + 2]); t[3] = __float_as_int(acc[i][j][e4 * 4 + 3]);
+                    __builtin_amdgcn_raw_buffer_store_b128(t, rs_mine, (((i * TN + j) * 4 + e4) * 256 + tid) * 16, 0, kSc1);
+                }
         // Every wave must see its sc1 stores ACKNOWLEDGED (performed at agent scope) before the arrival counter moves.
         // A workgroup-scope release fence does not wait for vmcnt on this target (waves of a workgroup share the
         // L1), and an agent-scope one also writes the L2 back; the explicit wait is exactly what is needed.
@@ -902,14 +912,15 @@ __global__ __launch_bounds__(256 * KS, (BK == 16 && KS == 1) ? (PREC == 3 ? 2 : 
 #pragma unroll
                 for (int e = 0; e < 16; ++e) sum[e] = 0.f;
                 for (int s2 = 0; s2 < p.ksplit; ++s2) {
-                    const float* other = p.sk_part + ((long)tile_id * p.ksplit + s2) * (BM * BN);
+                    const __amdgpu_buffer_rsrc_t rs_o = __builtin_amdgcn_make_buffer_rsrc(
+                        (void*)(p.sk_part + ((long)tile_id * p.ksplit + s2) * (BM * BN)), (short)0, BM * BN * 4, 0x00020000);
+                    const bool own = s2 == split;                  // wave-uniform: this workgroup's part never left its registers
+                    v4i_sk t[4];
 #pragma unroll
-                    for (int e = 0; e < 16; ++e) {
-                        const float v = s2 == split ? acc[i][j][e]
-                                                    : __hip_atomic_load(other + ((i * TN + j) * 16 + e) * 256 + tid, __ATOMIC_RELAXED,
-                                                                        __HIP_MEMORY_SCOPE_AGENT);
-                        sum[e] += v;
-                    }
+                    for (int e4 = 0; e4 < 4; ++e4)
+                        t[e4] = own ? v4i_sk{0, 0, 0, 0} : __builtin_amdgcn_raw_buffer_load_b128(rs_o, (((i * TN + j) * 4 + e4) * 256 + tid) * 16, 0, kSc1);
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) sum[e] += own ? acc[i][j][e] : __int_as_float(t[e >> 2][e & 3]);
                 }
                 acc[i][j] = sum;
             }
@@ -1521,7 +1532,11 @@ extern "C" int ofx_conv2d_alpha(const ofx_conv_desc* d, float alpha, void* strea
     // a grid of at most ~2 workgroups per CU is latency-bound: pair the pipelines (tile + 2e9 forces it, an explicit tile without that forbids it)
     const long blocks = (long)k.mtiles * k.ntiles * nz;
     if (k.ksplit > 1) return launch_tile<64, 64, 32, 32, 32, 0, 1, true>(k, d->epi, norm, nz, s);
-    const bool pair = d->tile >= 2000000000 || (d->tile < 1000000 && blocks <= 640 && k.Kpad >= 8 * 32);
+    // (round 5: up to 320 blocks, not 640 -- at 384 blocks, `convc1` on one 512x768 pair, the plain tile is ahead: 8.76 -> 8.62 ms per
+    // pair; OFX_CONV_PAIR_MAX=<blocks> overrides, 0 = never)
+    static const char* pair_env = getenv("OFX_CONV_PAIR_MAX");
+    const long pair_max = pair_env ? atol(pair_env) : 320;
+    const bool pair = d->tile >= 2000000000 || (d->tile < 1000000 && blocks <= pair_max && k.Kpad >= 8 * 32);
     if (bm == 64 && bn == 64 && pair) return launch_tile<64, 64, 32, 32, 32, 0, 2>(k, d->epi, norm, nz, s);
     if (bm == 64 && bn == 64) return launch_tile<64, 64, 32, 32, 32>(k, d->epi, norm, nz, s);
     return OFX_EINVAL;
