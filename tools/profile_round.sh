@@ -9,7 +9,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-COMMON="--no-cpu-baseline --no-single --no-fast --no-prof --no-handoff --no-verify"
+COMMON="--no-cpu-baseline --no-single --no-fast --no-prof --no-handoff --no-verify --no-sweep --no-pipeline"
 rocprofv3 --kernel-trace --stats -d $O/${TAG}_trace -o bench -- python $R/bench.py --steps 2 --warmup 1 $COMMON > $O/${TAG}_trace.log 2>&1
 tail -1 $O/${TAG}_trace.log | cut -c1-300
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/${TAG}_pmc_fetch -o pmc -- python $R/bench.py --steps 1 --warmup 0 $COMMON > $O/${TAG}_pmc_fetch.log 2>&1
