@@ -316,3 +316,40 @@ def test_edge_batches_and_io_thread_default(monkeypatch):
     assert pipeline.default_io_threads() == 6
     monkeypatch.setenv("LOCAL_WORLD_SIZE", "2")
     assert pipeline.default_io_threads() == 4
+
+
+def test_pipeline_run_failures_and_collective_guard(tmp_path, monkeypatch):
+    """`ClipPipeline.run`: a failing render hook surfaces as ITSELF (the writer's flush error must not replace it, its threads are
+    joined either way); under the `nccl` backend a pipeline built on a CPU device is refused before its first collective."""
+    import numpy as np
+    from sd_animation_optical_flow_amd import pipeline
+    video, _ = _make_workspace(str(tmp_path / "ws"), n=9)
+    flags = [True] + [False] * 8
+    pipe = _StubPipeline.make(batch=3, edge_batch=1)
+
+    class Boom(RuntimeError):
+        pass
+    seen = []
+    good = pipe.render
+
+    def render(pkt, raw):
+        seen.append(pkt.index)
+        if pkt.index == 5:
+            raise Boom("render failed on frame 5")
+        return good(pkt, raw)
+    pipe.render = render
+    # make the writer fail too: its error must stay in the background of the render failure
+    real_put = video.put_ai_frame
+    video.put_ai_frame = lambda i, f: (_ for _ in ()).throw(OSError("disk full")) if i == 2 else real_put(i, f)
+    with pytest.raises(Boom):
+        pipe.run(video, flags)
+    assert 5 in seen and 8 not in seen                      # stopped at the failure
+    video.put_ai_frame = real_put
+    pipe.render = good
+    assert pipe.run(video, flags) == [0]                    # the same pipeline object still works afterwards (no leaked slots / threads)
+    assert all(video.generated(i) for i in range(9))
+    # collective guard
+    import torch.distributed as tdist
+    monkeypatch.setattr(tdist, "get_backend", lambda group=None: "nccl")
+    with pytest.raises(RuntimeError, match="RCCL broadcasts need"):
+        pipe._check_collective()
