@@ -250,7 +250,7 @@ def _pipeline8_worker(rank, world, port, ws_a, ws_b):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     torch.set_num_threads(1)
-    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=90))
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=300))
     try:
         from sd_animation_optical_flow_amd.workspace import VideoData
         va = VideoData(None, (24, 16), ws_a)
