@@ -195,6 +195,7 @@ int ofx_abs_diff_sum_u8(const uint8_t* a, long a_bstride, const uint8_t* b, long
 #define OFX_PREC_FP32   0
 #define OFX_PREC_BF16X3 1
 #define OFX_PREC_BF16X3_W 2   /* bf16x3 with `w` already in the split format of ofx_split_conv_weight */
+#define OFX_PREC_BF16X6_W 4   /* bf16x6 with `w` already in the split format of ofx_split_conv_weight3 */
 #define OFX_PREC_BF16X6 3     /* opt-in: fp32 operands split into THREE bf16 pieces (exact), the six products of weight >= 2^-16
                                  on the bf16 matrix cores, fp32 accumulate: fp32-level accuracy (dropped terms < 2^-23), not the
                                  bit pattern of an fmaf chain */
@@ -237,6 +238,10 @@ long ofx_pack_conv_weight(const float* w_oihw, int Cout, int Cin, int KH, int KW
  * lo = bf16(x - hi), both round-to-nearest-even -- bit-identical to what the kernel's on-the-fly split makes.
  * Same size as the input; use with precision = OFX_PREC_BF16X3_W. Returns 0 or OFX_EINVAL. */
 int ofx_split_conv_weight(const float* packed, long n_floats, float* out);
+/* The same for the three-piece arithmetic (OFX_PREC_BF16X6_W): `out` holds 1.5 * n_floats floats -- first the [hi x4 | mid x4] groups
+ * (16 bytes per four consecutive k), then the [lo x4] groups (8 bytes per four k); hi + mid + lo = x exactly unless lo underflows.
+ * The whole matrix [Cout][Kpad] must be converted in one call (the lo groups are addressed from its end). */
+int ofx_split_conv_weight3(const float* packed, long n_floats, float* out);
 
 /* instance norm statistics over HW per (b,c): mean and 1/sqrt(var+eps) (biased var), NHWC input; C <= 256.
  * scratch: max(B*64, min(B,7)*256) * C * 2 doubles (f64 partial sums per image slice), 8-byte aligned. */

@@ -75,6 +75,7 @@ SIGNATURES = {
     "ofx_conv2d": (_i, [C.POINTER(ConvDesc), _p]),
     "ofx_pack_conv_weight": (_l, [_p, _i, _i, _i, _i, _i, _p]),
     "ofx_split_conv_weight": (_i, [_p, _l, _p]),
+    "ofx_split_conv_weight3": (_i, [_p, _l, _p]),
     "ofx_gaussian_blur_u8": (_i, [_p, _p, _p, _i, _i, _i, _f, _p]),
     "ofx_resize_bicubic_u8": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "ofx_sd_handoff": (_i, [_p] * 9 + [_i] * 5 + [_p]),

@@ -16,6 +16,8 @@
 //             bits), the six products of weight >= 2^-16 (hh, hm, mh, mm, hl, lh) on v_mfma_f32_32x32x16_bf16 with fp32
 //             accumulation: what is dropped (ml, lm, ll) is below 2^-23 relative, i.e. fp32 rounding level, at 2.7x the
 //             fp32 MFMA rate.  Not bit-identical to an fmaf chain; see DESIGN.md "Precision".
+//   PREC = 4  the same arithmetic as PREC = 3 with the WEIGHTS arriving pre-split (ofx_split_conv_weight3: [hi x4 | mid x4] groups, then
+//             the lo x4 groups): the B-side three-way split -- ~40 vector instructions per thread and tap -- leaves the kernel.
 //   PREC = 1  opt-in "bf16x3": every operand is split at LDS-commit time into hi = bf16(x) and
 //             lo = bf16(x - hi); hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_bf16, f32 accumulate
 //             (~16 mantissa bits per product; measured flow EPE ~1e-4 px after 20 iterations).
@@ -111,8 +113,9 @@ constexpr int kKAlign = 32;   // packed weights are zero-padded along K to this 
 // same products in another summation order.  Why it matters: the rate of the general kernel follows the A bytes staged per MFMA
 // (DESIGN.md section 4), which this cuts by the number of taps.
 template <int BM, int BN, int WM, int WN, int EPI, bool NORM, int BK, int PREC, int KS = 1, bool SK = false, int MODE = 0>
-__global__ __launch_bounds__(256 * KS, (BK == 16 && KS == 1) ? (PREC == 3 ? 2 : (PREC == 0 && BM <= 128 && BN <= 128 && !NORM && EPI != OFX_EPI_FLOW) ? 4 : 3) : 1) void igemm_kernel(const ConvK p) {
+__global__ __launch_bounds__(256 * KS, (BK == 16 && KS == 1) ? ((PREC == 3 || PREC == 4) ? 2 : (PREC == 0 && BM <= 128 && BN <= 128 && !NORM && EPI != OFX_EPI_FLOW) ? 4 : 3) : 1) void igemm_kernel(const ConvK p) {
     constexpr bool UK = MODE == 1, PATCH = MODE == 2;
+    constexpr bool X6 = PREC == 3 || PREC == 4;           // three bf16 pieces per operand, six products
     // halo patch rows staged per channel slab, rounded up to whole groups of 16: 8x16 patches 12 x 16 / 10 x 18 / 8 x 20 -> 192,
     // 8x8 patches (the 64-row tile) 12 x 8 / 10 x 10 / 8 x 12 -> 112
     // (the 256-row tile: 16x16 patches, 20 x 16 / 18 x 18 / 16 x 20 -> 336)
@@ -130,12 +133,12 @@ __global__ __launch_bounds__(256 * KS, (BK == 16 && KS == 1) ? (PREC == 3 ? 2 : 
     // PREC = 1 (bf16x3): every fp32 operand element is staged as two bf16 values hi = bf16(x), lo = bf16(x - hi)
     // (same 4 bytes per element); rows are BK bf16 + 16 B of padding (48 B / 80 B: conflict-free b128 reads)
     constexpr int ROWB = BK * 2 + 16;                       // bytes per staged bf16 row
-    constexpr int NPC = PREC == 3 ? 3 : 2;                  // bf16 pieces per operand element
+    constexpr int NPC = X6 ? 3 : 2;                         // bf16 pieces per operand element
     constexpr int STAGE = PREC ? ((BM + BN_ST) * ROWB * NPC) / 4 : (BM + BN_ST) * LDK;   // floats per stage
     static_assert((BM / WM) * (BN / WN) == 4, "4 waves per workgroup");
     static_assert(KS == 1 || KS == 2, "one or two pipelines");
     static_assert(KS == 1 || 2 * STAGE * KS >= 256 * TM * TN * 16, "accumulator exchange must fit the staging buffers");
-    __shared__ __attribute__((aligned(16))) float smem_all[!PATCH ? 2 * STAGE * KS : PREC == 0 ? (kPatchRows + 2 * BN_ST) * LDK : (kPatchRows + 2 * BN_ST) * (PREC == 3 ? 3 : 2) * (ROWB / 4)];
+    __shared__ __attribute__((aligned(16))) float smem_all[!PATCH ? 2 * STAGE * KS : PREC == 0 ? (kPatchRows + 2 * BN_ST) * LDK : (kPatchRows + 2 * BN_ST) * (X6 ? 3 : 2) * (ROWB / 4)];
     const int grp = KS == 1 ? 0 : (int)(threadIdx.x >> 8);      // pipeline this thread belongs to
     float* const smem = smem_all + grp * (2 * STAGE);
 
@@ -190,6 +193,8 @@ __global__ __launch_bounds__(256 * KS, (BK == 16 && KS == 1) ? (PREC == 3 ? 2 : 
     const float* in1s = in1 ? in1 : in0;
     const int bytes1s = in1 ? p.bytes1 : p.bytes0;
     const __amdgpu_buffer_rsrc_t rsrcw = __builtin_amdgcn_make_buffer_rsrc((void*)wgt, (short)0, p.bytesw, 0x00020000);
+    // PREC = 4: the lo x4 groups of the pre-split weights sit behind the [hi x4 | mid x4] groups, 8 bytes per four k (half the offsets)
+    const __amdgpu_buffer_rsrc_t rsrcw2 = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)wgt + (PREC == 4 ? p.bytesw : 0)), (short)0, p.bytesw >> 1, 0x00020000);
     constexpr int kOOB = 0x7FFFFFF0;
 
     // ---- per-thread gather coordinates for the A (im2col) tile
@@ -255,7 +260,7 @@ __global__ __launch_bounds__(256 * KS, (BK == 16 && KS == 1) ? (PREC == 3 ? 2 : 
     }
 
     if constexpr (PATCH) {
-        static_assert(!PATCH || (PREC <= 3 && KS == 1 && ((BM == 128 && (WM == 64 || WM == 32) && BK == 16 && !SK) || (PREC == 0 && BM == 64 && WM == 32 && BK == 32) ||
+        static_assert(!PATCH || (PREC <= 4 && KS == 1 && ((BM == 128 && (WM == 64 || WM == 32) && BK == 16 && !SK) || (PREC == 0 && BM == 64 && WM == 32 && BK == 32) ||
                                                          (PREC == 0 && BM == 256 && WM == 64 && BK == 16 && !SK))),
                       "patch mode: 128-row tiles with 16-channel slabs (fp32 or bf16x3), or the fp32 64x64 small-grid tile with 32-channel slabs (split-K allowed)");
         static_assert(!PATCH || (EPI != OFX_EPI_FLOW && EPI != kEpiVolPool), "patch mode: plain / GRU epilogues");
@@ -273,7 +278,7 @@ __global__ __launch_bounds__(256 * KS, (BK == 16 && KS == 1) ? (PREC == 3 ? 2 : 
         constexpr int APIECE = kPatchRows * AROWF;           // floats per A piece
         constexpr int BPIECE = BN_ST * AROWF;
         float* const Apatch = smem_all;
-        constexpr int NPIECE = PREC == 0 ? 1 : PREC == 3 ? 3 : 2;
+        constexpr int NPIECE = PREC == 0 ? 1 : X6 ? 3 : 2;
         float* const Bst = smem_all + NPIECE * APIECE;
         constexpr int BSTAGE = NPIECE * BPIECE;
         // the (row, float4 slot) pairs this thread stages per slab; rows permuted like r0 (conflict-free ds_write_b128)
@@ -345,6 +350,7 @@ __global__ __launch_bounds__(256 * KS, (BK == 16 && KS == 1) ? (PREC == 3 ? 2 : 
         float4 pa[NSLOT];
         float4 pmu = make_float4(0.f, 0.f, 0.f, 0.f), prs = pmu;
         float4 rb0 = make_float4(0.f, 0.f, 0.f, 0.f), rb1 = rb0, rb2 = rb0, rb3 = rb0;
+        float2 rl0 = make_float2(0.f, 0.f), rl1 = rl0, rl2 = rl0, rl3 = rl0;      // PREC = 4: the lo pieces
         auto a_issue = [&](int cb) __attribute__((always_inline)) {
             const int c = cb * BK;
             const bool s0 = c < p.c0;                        // wave-uniform
@@ -380,7 +386,7 @@ __global__ __launch_bounds__(256 * KS, (BK == 16 && KS == 1) ? (PREC == 3 ? 2 : 
                     *reinterpret_cast<float4*>(&Apatch[alds0 + q * SROWS * LDK]) = v;
                 } else {
                     char* hi = reinterpret_cast<char*>(Apatch) + alds0 + q * SROWS * ROWB;
-                    if constexpr (PREC == 3) split_store3(hi, hi + APIECE * 4, hi + 2 * APIECE * 4, v);
+                    if constexpr (X6) split_store3(hi, hi + APIECE * 4, hi + 2 * APIECE * 4, v);
                     else split_store(hi, hi + APIECE * 4, v);
                 }
             }
@@ -390,7 +396,8 @@ __global__ __launch_bounds__(256 * KS, (BK == 16 && KS == 1) ? (PREC == 3 ? 2 : 
         auto b_issue = [&]() __attribute__((always_inline)) {
             const int so = (itap * p.cin + icb * BK) * 4;
 #define OFX_B_ISSUE(i) \
-    if constexpr (B_PER > i) { v4i t = __builtin_amdgcn_raw_buffer_load_b128(rsrcw, browb[i], so, 0); rb##i = *reinterpret_cast<float4*>(&t); }
+    if constexpr (B_PER > i) { v4i t = __builtin_amdgcn_raw_buffer_load_b128(rsrcw, browb[i], so, 0); rb##i = *reinterpret_cast<float4*>(&t); \
+        if constexpr (PREC == 4) { typedef int v2i_ __attribute__((ext_vector_type(2))); v2i_ u = __builtin_amdgcn_raw_buffer_load_b64(rsrcw2, browb[i] >> 1, so >> 1, 0); rl##i = *reinterpret_cast<float2*>(&u); } }
             OFX_B_ISSUE(0) OFX_B_ISSUE(1) OFX_B_ISSUE(2) OFX_B_ISSUE(3)
 #undef OFX_B_ISSUE
             if (icb + 1 < CB || itap + 1 < T) {              // past the last chunk: keep re-issuing it (never multiplied)
@@ -413,6 +420,10 @@ __global__ __launch_bounds__(256 * KS, (BK == 16 && KS == 1) ? (PREC == 3 ? 2 : 
         if constexpr (PREC == 2) { \
             *reinterpret_cast<float2*>(b_hi + o) = make_float2(rb##i.x, rb##i.y); \
             *reinterpret_cast<float2*>(b_lo + o) = make_float2(rb##i.z, rb##i.w); \
+        } else if constexpr (PREC == 4) { \
+            *reinterpret_cast<float2*>(b_hi + o) = make_float2(rb##i.x, rb##i.y); \
+            *reinterpret_cast<float2*>(b_lo + o) = make_float2(rb##i.z, rb##i.w); \
+            *reinterpret_cast<float2*>(b_lo + BPIECE * 4 + o) = rl##i; \
         } else if constexpr (PREC == 3) { \
             split_store3(b_hi + o, b_lo + o, b_lo + BPIECE * 4 + o, rb##i); \
         } else { \
@@ -425,7 +436,7 @@ __global__ __launch_bounds__(256 * KS, (BK == 16 && KS == 1) ? (PREC == 3 ? 2 : 
         };
 
         auto step = [&](int c, int ky, int kx) __attribute__((always_inline)) {
-            if constexpr (PREC == 3) {
+            if constexpr (X6) {
                 // bf16x6 on the patch: pieces (hi, mid, lo) in that order; the six products of weight >= 2^-16, smallest first
                 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
                 const char* a0 = reinterpret_cast<const char*>(Apatch) + (ky * PWH + kx) * ROWB;
@@ -549,6 +560,7 @@ __global__ __launch_bounds__(256 * KS, (BK == 16 && KS == 1) ? (PREC == 3 ? 2 : 
     // ---- pipeline registers (chunk in flight between `issue` and `commit`)
     float4 ra[A_PER];
     float4 rb0 = make_float4(0.f, 0.f, 0.f, 0.f), rb1 = rb0, rb2 = rb0, rb3 = rb0;   // named scalars: see OFX_B_* below
+    float2 rl0 = make_float2(0.f, 0.f), rl1 = rl0, rl2 = rl0, rl3 = rl0;             // PREC = 4: the lo pieces of the pre-split weights
     float4 rmu[NORM ? A_PER : 1], rrs[NORM ? A_PER : 1];
     unsigned okbits = 0;
     int voffa[A_PER], voffb[B_PER];
@@ -637,7 +649,8 @@ __global__ __launch_bounds__(256 * KS, (BK == 16 && KS == 1) ? (PREC == 3 ? 2 : 
             okbits >>= 16;   // the chunk just issued becomes the one the next commit sees
         }
 #define OFX_B_ISSUE(i) \
-    if constexpr (B_PER > i) { v4i t = __builtin_amdgcn_raw_buffer_load_b128(rsrcw, voffb[i], 0, 0); rb##i = *reinterpret_cast<float4*>(&t); }
+    if constexpr (B_PER > i) { v4i t = __builtin_amdgcn_raw_buffer_load_b128(rsrcw, voffb[i], 0, 0); rb##i = *reinterpret_cast<float4*>(&t); \
+        if constexpr (PREC == 4) { typedef int v2i_ __attribute__((ext_vector_type(2))); v2i_ u = __builtin_amdgcn_raw_buffer_load_b64(rsrcw2, voffb[i] >> 1, 0, 0); rl##i = *reinterpret_cast<float2*>(&u); } }
         OFX_B_ISSUE(0) OFX_B_ISSUE(1) OFX_B_ISSUE(2) OFX_B_ISSUE(3)
 #undef OFX_B_ISSUE
     };
@@ -681,7 +694,7 @@ __global__ __launch_bounds__(256 * KS, (BK == 16 && KS == 1) ? (PREC == 3 ? 2 : 
     };
 
     auto commit = [&](float* stage) __attribute__((always_inline)) {
-        if constexpr (PREC == 3) {
+        if constexpr (X6) {
             char* a0 = reinterpret_cast<char*>(stage);
             char* b0 = a0 + 3 * BM * ROWB;
 #pragma unroll
@@ -692,7 +705,13 @@ __global__ __launch_bounds__(256 * KS, (BK == 16 && KS == 1) ? (PREC == 3 ? 2 : 
 #define OFX_B_COMMIT(i) \
     if constexpr (B_PER > i) { \
         const int o = (r0 + RPG * i) * ROWB + kq * 8; \
-        split_store3(b0 + o, b0 + BN_ST * ROWB + o, b0 + 2 * BN_ST * ROWB + o, rb##i); \
+        if constexpr (PREC == 4) { \
+            *reinterpret_cast<float2*>(b0 + o) = make_float2(rb##i.x, rb##i.y); \
+            *reinterpret_cast<float2*>(b0 + BN_ST * ROWB + o) = make_float2(rb##i.z, rb##i.w); \
+            *reinterpret_cast<float2*>(b0 + 2 * BN_ST * ROWB + o) = rl##i; \
+        } else { \
+            split_store3(b0 + o, b0 + BN_ST * ROWB + o, b0 + 2 * BN_ST * ROWB + o, rb##i); \
+        } \
     }
             OFX_B_COMMIT(0) OFX_B_COMMIT(1) OFX_B_COMMIT(2) OFX_B_COMMIT(3)
 #undef OFX_B_COMMIT
@@ -765,7 +784,7 @@ __global__ __launch_bounds__(256 * KS, (BK == 16 && KS == 1) ? (PREC == 3 ? 2 : 
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].w, fb[j].w, acc[i][j], 0, 0, 0);
                     }
             }
-        } else if constexpr (PREC == 3) {
+        } else if constexpr (X6) {
             // bf16x6: the six products of weight >= 2^-16, smallest first, fp32 accumulate
             typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
             const char* a0 = reinterpret_cast<const char*>(smem + (kt & 1) * STAGE);
@@ -1174,7 +1193,7 @@ template <int BM, int BN, int WM, int WN, int BK, int PREC = 0, int KS = 1, bool
 int launch_tile(const ConvK& k, int epi, bool norm, int nz, hipStream_t s) {
     if constexpr (KS == 1 && ((PREC == 0 && BM == 128 && BK == 16 && !SK && (BN == 64 || BN == 96 || BN == 128 || BN == 192)) || (PREC == 0 && BM == 64 && BN == 64 && BK == 32) ||
                               (PREC == 0 && BM == 256 && BN == 64 && BK == 16 && !SK) ||
-                              ((PREC == 1 || PREC == 2 || PREC == 3) && BM == 128 && BK == 16 && !SK && (BN == 64 || BN == 128)))) {
+                              ((PREC == 1 || PREC == 2 || PREC == 3 || PREC == 4) && BM == 128 && BK == 16 && !SK && (BN == 64 || BN == 128)))) {
         if (k.patch && epi != OFX_EPI_FLOW && epi != kEpiVolPool) return launch_tile_uk<BM, BN, WM, WN, BK, PREC, KS, SK, 2>(k, epi, norm, nz, s);
     }
     if constexpr (PREC == 0 && BN != 192) {   // the 128x192 tile measured 0.8 % slower with scalar chunk coordinates
@@ -1493,9 +1512,15 @@ extern "C" int ofx_conv2d_alpha(const ofx_conv_desc* d, float alpha, void* strea
             k.ntiles = (d->Cout + 127) / 128;
             k.group_m = k.ntiles >= 8 ? 8 : 1;
             k.ksplit = 1;
-            if (d->precision == OFX_PREC_BF16X6) return launch_tile<128, 128, 64, 64, 16, 3>(k, kEpiVolPool, false, nz, s);
+            if (d->precision == OFX_PREC_BF16X6 || d->precision == OFX_PREC_BF16X6_W) return launch_tile<128, 128, 64, 64, 16, 3>(k, kEpiVolPool, false, nz, s);   // (its B operand is data, never pre-split)
             if (d->precision == OFX_PREC_BF16X3_W) return launch_tile<128, 128, 64, 64, 16, 2>(k, kEpiVolPool, false, nz, s);
             return launch_tile<128, 128, 64, 64, 16, 1>(k, kEpiVolPool, false, nz, s);
+        }
+        if (d->precision == OFX_PREC_BF16X6_W) {       // bf16x6 with the weights pre-split (ofx_split_conv_weight3)
+            if (bm == 128 && bn == 128) return launch_tile<128, 128, 64, 64, 16, 4>(k, d->epi, norm, nz, s);
+            if (bm == 128 && bn == 64) return launch_tile<128, 64, 64, 32, 16, 4>(k, d->epi, norm, nz, s);
+            if (bm == 64 && bn == 64) return launch_tile<64, 64, 32, 32, 16, 4>(k, d->epi, norm, nz, s);
+            return OFX_EINVAL;
         }
         if (d->precision == OFX_PREC_BF16X6) {
             if (bm == 128 && bn == 128) return launch_tile<128, 128, 64, 64, 16, 3>(k, d->epi, norm, nz, s);
@@ -1567,6 +1592,27 @@ extern "C" int ofx_split_conv_weight(const float* packed, long n, float* out) {
             const volatile float rem = x - bf16_to_f32(hi);       // exact in fp32; volatile: no contraction / reassociation
             o[2 * g + i] = hi;
             o[2 * g + 4 + i] = bf16_rne(rem);
+        }
+    return 0;
+}
+
+// packed fp32 weights [n] -> the bf16x6 operand format: n floats of [hi x4 | mid x4] groups (16 bytes per four consecutive k, the layout
+// of ofx_split_conv_weight with mid in lo's place), then n / 2 floats of [lo x4] groups (8 bytes per four k).  hi = bf16(x),
+// mid = bf16(x - hi), lo = bf16(x - hi - mid), each round-to-nearest-even: the pieces the kernel's on-the-fly split makes
+extern "C" int ofx_split_conv_weight3(const float* packed, long n, float* out) {
+    if (!packed || !out || n <= 0 || (n & 3)) return OFX_EINVAL;
+    uint16_t* o = reinterpret_cast<uint16_t*>(out);
+    uint16_t* o2 = o + 2 * n;
+    for (long g = 0; g < n; g += 4)
+        for (int i = 0; i < 4; ++i) {
+            const float x = packed[g + i];
+            const uint16_t hi = bf16_rne(x);
+            const volatile float r1 = x - bf16_to_f32(hi);        // exact in fp32; volatile: no contraction / reassociation
+            const uint16_t mid = bf16_rne(r1);
+            const volatile float r2 = r1 - bf16_to_f32(mid);
+            o[2 * g + i] = hi;
+            o[2 * g + 4 + i] = mid;
+            o2[g + i] = bf16_rne(r2);
         }
     return 0;
 }

@@ -33,6 +33,7 @@ namespace {
 struct ConvW {
     float* w = nullptr;       // [Cout][Kpad]
     float* wsplit = nullptr;  // the same matrix pre-split into bf16 (hi, lo) quads for the bf16x3 mode
+    float* wsplit3 = nullptr; // ... and into (hi, mid | lo) for the bf16x6 mode (ofx_split_conv_weight3: 1.5 x the floats)
     float* scale = nullptr;   // [Cout] or null
     float* shift = nullptr;   // [Cout] or null
     int cout = 0, cin = 0, cin_pad = 0, kh = 0, kw = 0;
@@ -128,7 +129,12 @@ int upload_weight(ofx_raft* r, const std::vector<float>& packed, ConvW* c) {
     std::vector<float> sp(packed.size());
     st = ofx_split_conv_weight(packed.data(), (long)packed.size(), sp.data());
     if (st) return st;
-    return upload(r, sp, &c->wsplit);
+    st = upload(r, sp, &c->wsplit);
+    if (st) return st;
+    std::vector<float> sp3(packed.size() * 3 / 2);
+    st = ofx_split_conv_weight3(packed.data(), (long)packed.size(), sp3.data());
+    if (st) return st;
+    return upload(r, sp3, &c->wsplit3);
 }
 
 const HostTensor* find(const std::map<std::string, HostTensor>& sd, const std::string& k) {
@@ -323,7 +329,9 @@ struct Launcher {
         d.in1 = in1; d.ld1 = ld1; d.c1 = c1;
         const int cout = rows ? rows : c.cout;
         const bool wsplit = precision == OFX_PREC_BF16X3 && c.wsplit != nullptr;
-        d.w = (wsplit ? c.wsplit : c.w) + (long)row_off * c.kpad;
+        // (the three-piece format addresses its lo groups from the end of the whole matrix: row slices keep the on-the-fly split)
+        const bool wsplit3 = precision == OFX_PREC_BF16X6 && c.wsplit3 != nullptr && row_off == 0 && rows == 0;
+        d.w = wsplit3 ? c.wsplit3 : (wsplit ? c.wsplit : c.w) + (long)row_off * c.kpad;
         d.scale = c.scale ? c.scale + row_off : nullptr;
         d.shift = c.shift ? c.shift + row_off : nullptr;
         d.out = out; d.ldo = ldo;
@@ -339,7 +347,7 @@ struct Launcher {
         d.Wout = (Win + 2 * padW - c.kw) / stride + 1;
         d.Cout = cout; d.KH = c.kh; d.KW = c.kw; d.stride = stride; d.padH = padH; d.padW = padW;
         d.act = act; d.epi = epi;
-        d.precision = wsplit ? OFX_PREC_BF16X3_W : precision;
+        d.precision = wsplit3 ? OFX_PREC_BF16X6_W : wsplit ? OFX_PREC_BF16X3_W : precision;
         d.splitk_ws = sk_ws; d.splitk_ws_bytes = sk_bytes;
         if (c0 + c1 != c.cin_pad) { st = OFX_EKEY; return; }
         ofx_prof_set_tag(c.name.c_str());

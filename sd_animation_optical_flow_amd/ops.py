@@ -246,6 +246,15 @@ def split_conv_weight(w_packed: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def split_conv_weight3(w_packed: torch.Tensor) -> torch.Tensor:
+    """Packed fp32 weights (CPU, the whole [Cout, Kpad] matrix) -> the pre-split bf16x6 operand format: a flat fp32 container of
+    1.5 x the size ([hi x4 | mid x4] groups, then the [lo x4] groups); feed it to conv2d_nhwc(..., precision="bf16x6_w")."""
+    w = w_packed.detach().to(torch.float32).contiguous().cpu()
+    out = torch.empty((w.numel() * 3 // 2,), dtype=torch.float32)
+    check(_lib.lib().ofx_split_conv_weight3(C.c_void_p(w.data_ptr()), w.numel(), C.c_void_p(out.data_ptr())), "ofx_split_conv_weight3")
+    return out
+
+
 def conv2d_nhwc(x: torch.Tensor, w_packed: torch.Tensor, kh: int, kw: int, cout: int, *, stride: int = 1,
                 shift: Optional[torch.Tensor] = None, scale: Optional[torch.Tensor] = None, act: Optional[str] = None,
                 x2: Optional[torch.Tensor] = None, res: Optional[torch.Tensor] = None,
@@ -286,7 +295,7 @@ def conv2d_nhwc(x: torch.Tensor, w_packed: torch.Tensor, kh: int, kw: int, cout:
     d.B, d.Hin, d.Win, d.Hout, d.Wout, d.Cout = B, H, W, Ho, Wo, cout
     d.KH, d.KW, d.stride, d.padH, d.padW = kh, kw, stride, ph, pw
     d.act, d.epi, d.tile = ACTS[act], EPI_PLAIN, tile
-    d.precision = {"fp32": 0, "bf16x3": 1, "bf16x3_w": 2, "bf16x6": 3}[precision]   # bf16x3_w: weight from split_conv_weight
+    d.precision = {"fp32": 0, "bf16x3": 1, "bf16x3_w": 2, "bf16x6": 3, "bf16x6_w": 4}[precision]   # *_w: weight from split_conv_weight(3)
     if splitk_ws is not None:       # uint8 scratch whose first 64 KiB are zero (see ofx_conv_desc.splitk_ws): allows split-K
         ws = _chk(splitk_ws, "splitk_ws", torch.uint8)
         d.splitk_ws, d.splitk_ws_bytes = ws.data_ptr(), ws.numel()

@@ -159,6 +159,9 @@ def test_conv2d_bf16x6_mode_is_fp32_accurate(cuda, case):
     e6 = (nchw(out6) - ref).abs().max().item()
     assert e32 < 2e-5 and e6 < 2e-5 and e6 < 3 * e32 + 1e-6, (e32, e6)
     assert not torch.equal(out6, out32)                      # a different summation, not the fp32 kernel by accident
+    # pre-split weights (round 5; what the executor uploads once): the same three pieces -> bit-identical to the on-the-fly split
+    out6w = ops.conv2d_nhwc(xin, ops.split_conv_weight3(wp.cpu()).cuda(), kh, kw, co, stride=stride, shift=b.cuda(), precision="bf16x6_w")
+    assert torch.equal(out6w, out6)
 
 
 @pytest.mark.parametrize("case", [  # B, H, W, c0, c1, cout, kh, kw, tile
@@ -265,6 +268,8 @@ def test_conv2d_halo_patch_kernel_bf16x6(cuda, case):
     e6 = (nchw(out6) - ref).abs().max().item()
     assert e32 < 2e-5 and e6 < 2e-5 and e6 < 3 * e32 + 1e-6, (e32, e6)
     assert not torch.equal(out6, out32)
+    out6w = ops.conv2d_nhwc(nhwc(xa), ops.split_conv_weight3(wp.cpu()).cuda(), kh, kw, co, tile=tile, precision="bf16x6_w", **kwargs)
+    assert torch.equal(out6w, out6)                          # pre-split weights on the halo patch: the same pieces, the same bits
 
 
 def test_conv2d_randomised_sweep_over_schedules(cuda):
