@@ -267,6 +267,13 @@ int ofx_preprocess_u8(const uint8_t* img, float* out, long npix, int bgr, void* 
 int ofx_corr_slice_floats(int h_l, int w_l);      /* ceil(h_l/4) * ceil(w_l/8) * 32 */
 int ofx_corr_volume(const float* f1, const float* f2, float* const* pyr, int B, int h, int w, int D,
                     int levels, void* stream);
+/* The same pyramid with the volume GEMM in split-bf16 arithmetic (opt-in; RAFT/core/corr.py:52-60 computes it in fp32):
+ * planes = 2 -> "bf16x3" (each fp32 operand = hi + lo bf16; products hh + hl + lh, ~16 mantissa bits),
+ * planes = 3 -> "bf16x6" (hi + mid + lo; the six products >= 2^-16: fp32-level accuracy) on v_mfma_f32_32x32x16_bf16 with fp32
+ * accumulation.  shared_f2 != 0: f2 is ONE feature map [h*w, D] shared by the B pairs (a key frame).  Needs D == 256, h % 8 == 0,
+ * w % 16 == 0, levels >= 2 and (h*w)^2 * 4 < 2 GiB per pair; anything else returns OFX_EINVAL (use ofx_corr_volume). */
+int ofx_corr_volume_split(const float* f1, const float* f2, float* const* pyr, int B, int h, int w, int D,
+                          int levels, int planes, int shared_f2, void* stream);
 /* CorrBlock.__call__ on the blocked pyramid: out[m, l*(2r+1)^2 + i*(2r+1) + j] for coords [B*h*w][2];
  * out row stride ldo */
 int ofx_corr_lookup(const float* const* pyr, const float* coords, float* out, int ldo, int B, int h,
@@ -322,6 +329,9 @@ size_t ofx_raft_workspace_bytes(const ofx_raft* r, int B, int H, int W);
                                      a model never put in .eval(), one image per call) instead of the folded running statistics */
 #define OFX_RAFT_SEPARATE_STATS 256 /* diagnostic: instance-norm statistics by their own f64 pass over the stored tensor instead of
                                      out of the convolution epilogues (fp32 partial sums per wave) */
+#define OFX_RAFT_VOL_BF16X3  512  /* opt-in: ONLY the correlation-volume GEMM in split-bf16 (hi + lo) arithmetic, operands pre-split into
+                                     bf16 planes (ofx_corr_volume_split); every convolution stays exact fp32 */
+#define OFX_RAFT_VOL_BF16X6 1024  /* the same with three planes per operand (fp32-level accuracy) */
 #define OFX_RAFT_SERIAL       32  /* keep every launch on the caller's stream (default: small batches run their
                                      independent chains on internal side streams, joined before returning) */
 

@@ -92,6 +92,7 @@ SIGNATURES = {
     "ofx_attention_f32": (_i, [_p, _p, _p, _p, C.c_long, _p, _i, _i, _i, _i, C.c_float, _p, C.c_size_t, _p]),
     "ofx_corr_slice_floats": (_i, [_i, _i]),
     "ofx_corr_volume": (_i, [_p, _p, C.POINTER(_p), _i, _i, _i, _i, _i, _p]),
+    "ofx_corr_volume_split": (_i, [_p, _p, C.POINTER(_p), _i, _i, _i, _i, _i, _i, _i, _p]),
     "ofx_corr_lookup": (_i, [C.POINTER(_p), _p, _p, _i, _i, _i, _i, _i, _i, _p]),
     "ofx_local_corr_fwd": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
     "ofx_local_corr_bwd": (_i, [_p] * 6 + [_i] * 8 + [_p]),

@@ -69,6 +69,14 @@ int ofx_corr_block_rows(const float* src, float* dst, int n, int h, int w, int D
 int ofx_corr_pool_launch(const float* l0, float* l1, float* l2, float* l3, int B, int h, int w, int levels, hipStream_t s,
                          bool from_l1 = false);
 bool ofx_corr_volpool_ok(int h, int w);
+// corr_split.hip: the volume GEMM in split-bf16 form (opt-in `volume_precision`): fp32 rows -> bf16 planes in MFMA fragment order
+// (planes = 2: bf16x3, 3: bf16x6; quad = 1: rows in the quad-blocked column order of the streamed operand), and the A-stationary GEMM
+// that writes level 0 (blocked) and level 1 of nz pairs.  ia / ib: device arrays of image indices per pair, or null with byte strides
+bool ofx_corr_volsplit_ok(int h, int w, int D);
+size_t ofx_corr_planes_bytes(int h, int w, int planes);
+int ofx_corr_split_planes(const float* src, void* dst, int n, int h, int w, int planes, int quad, float alpha, hipStream_t s);
+int ofx_corr_vol_split_launch(const void* ap, const void* bp, const int* ia, const int* ib, long a_zs, long b_zs, float* l0, float* l1,
+                              int nz, int h, int w, int planes, hipStream_t s);
 // mask_bits.hip: binary threshold/edge source -> elliptical dilation on bit planes
 enum { OFX_MSRC_CONF_LT = 0, OFX_MSRC_CONF_NGT = 1, OFX_MSRC_EDGES = 3 };   // conf < t | !(conf > t) | Laplacian edges
 int ofx_mask_bits_launch(int src, const float* conf, float* log_conf, const uint8_t* image, const uint8_t* or_mask,

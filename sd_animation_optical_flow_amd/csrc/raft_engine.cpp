@@ -552,7 +552,7 @@ static RaftWs carve(void* base, size_t cap, int B, int H, int W, int flags, int 
         n1 = n_images;
         n2 = 0;
         w.ctx = c.take((size_t)n_images * N * (HD + CD));
-        w.idx_dev = (int*)c.take((size_t)B);
+        w.idx_dev = (int*)c.take((size_t)2 * B);   // image1 indices, then image2 indices
     }
     w.fmap1 = c.take((size_t)n1 * N * FD);
     w.fmap2 = n2 ? c.take((size_t)n2 * N * FD) : w.fmap1;
@@ -675,6 +675,16 @@ static int run_recurrence(ofx_raft* r, const RaftWs& ws, int B, int h, int w, in
     }
 
     return 0;
+}
+
+// The volume GEMM in split-bf16 form (corr_split.hip): OFX_RAFT_VOL_BF16X3 / _BF16X6 ask for it alone (every convolution stays fp32),
+// the all-layer split modes take it along.  Its operand planes live in the recurrence's scratch (corr ... mask: dead until the first
+// iteration).  0 planes = the fp32 / generic path.
+static int volume_planes(int flags, int h, int w, long n_planes_images, const RaftWs& ws, long M) {
+    const int planes = (flags & (OFX_RAFT_VOL_BF16X6 | OFX_RAFT_BF16X6)) ? 3 : (flags & (OFX_RAFT_VOL_BF16X3 | OFX_RAFT_BF16X3)) ? 2 : 0;
+    if (!planes || !ofx_corr_volsplit_ok(h, w, FD) || getenv("OFX_NO_VOLSPLIT")) return 0;
+    const size_t room = (size_t)((const char*)(ws.mask + M * 576) - (const char*)ws.corr);
+    return (size_t)n_planes_images * ofx_corr_planes_bytes(h, w, planes) <= room ? planes : 0;
 }
 
 static int raft_forward_impl(ofx_raft* r, const uint8_t* image1, const uint8_t* image2, int B, int H, int W, int iters, int flags,
@@ -860,7 +870,17 @@ static int raft_forward_impl(ofx_raft* r, const uint8_t* image1, const uint8_t* 
     if (st) return st;
 
     // ---- correlation
-    if (!alt) {
+    const int vplanes = alt ? 0 : volume_planes(flags, h, w, (long)n1 + n2, ws, M);
+    if (vplanes) {
+        char* pl = (char*)ws.corr;
+        const long ib = (long)ofx_corr_planes_bytes(h, w, vplanes);
+        st = ofx_corr_split_planes(ws.fmap1, pl, n1, h, w, vplanes, 0, 1.0f / std::sqrt((float)FD), s);
+        if (!st) st = ofx_corr_split_planes(ws.fmap2, pl + ib * n1, n2, h, w, vplanes, 1, 1.0f, s);
+        if (!st)
+            st = ofx_corr_vol_split_launch(pl, pl + ib * n1, nullptr, nullptr, sh1 ? 0 : ib, sh2 ? 0 : ib, ws.pyr[0], ws.pyr[1], B, h, w, vplanes, s);
+        if (!st) st = ofx_corr_pool_launch(ws.pyr[0], ws.pyr[1], ws.pyr[2], ws.pyr[3], B, h, w, LEVELS, s, true);
+        if (st) return st;
+    } else if (!alt) {
         // the volume's columns in blocked order: permute the rows of the B operand once (6.3 MB per image)
         const long Nb = ofx_corr_slice_floats_l(h, w);
         st = ofx_corr_block_rows(ws.fmap2, ws.fmap2b, (int)n2, h, w, FD, s);
@@ -981,11 +1001,23 @@ int ofx_raft_forward_pairs_warp(ofx_raft* r, const uint8_t* images, int n_images
     st = ofx_ctx_gather(ws.ctx, ws.idx_dev, ws.hx, HX_LD, INP_OFF, HD, B, N, s);
     if (st) return st;
     const long Nb = ofx_corr_slice_floats_l(h, w);
-    st = ofx_corr_block_rows(ws.fmap1, ws.fmap2b, n_images, h, w, FD, s);   // every image can be an image2: blocked copy of all
-    if (st) return st;
     const long slice1p = ofx_corr_slice_floats_l(h >> 1, w >> 1);
     const bool fused_pairs = ofx_corr_volpool_ok(h, w) && Nb % 128 == 0 && N * slice1p * 4 < (1L << 31) - 64;
-    for (int b = 0; b < B && !st; ++b) {   // one N x Nb correlation GEMM per pair, straight from the shared feature maps
+    const int vplanes = volume_planes(flags, h, w, 2L * n_images, ws, (long)B * N);
+    if (vplanes) {
+        // split-bf16 volume: every image split once per role (rows scaled in pixel order / columns in quad order), ONE launch over the
+        // pair list through the device-side index arrays
+        char* pl = (char*)ws.corr;
+        const long ib = (long)ofx_corr_planes_bytes(h, w, vplanes);
+        OFX_HIP_CHECK(hipMemcpyAsync(ws.idx_dev + B, idx2, sizeof(int) * B, hipMemcpyHostToDevice, s));
+        st = ofx_corr_split_planes(ws.fmap1, pl, n_images, h, w, vplanes, 0, 1.0f / std::sqrt((float)FD), s);
+        if (!st) st = ofx_corr_split_planes(ws.fmap1, pl + ib * n_images, n_images, h, w, vplanes, 1, 1.0f, s);
+        if (!st) st = ofx_corr_vol_split_launch(pl, pl + ib * n_images, ws.idx_dev, ws.idx_dev + B, 0, 0, ws.pyr[0], ws.pyr[1], B, h, w, vplanes, s);
+    } else {
+        st = ofx_corr_block_rows(ws.fmap1, ws.fmap2b, n_images, h, w, FD, s);   // every image can be an image2: blocked copy of all
+    }
+    if (st) return st;
+    for (int b = 0; b < B && !st && !vplanes; ++b) {   // one N x Nb correlation GEMM per pair, straight from the shared feature maps
         ofx_conv_desc d{};
         d.in0 = ws.fmap1 + (long)idx1[b] * N * FD; d.ld0 = FD; d.c0 = FD;
         d.w = ws.fmap2b + (long)idx2[b] * Nb * FD;
@@ -1000,7 +1032,7 @@ int ofx_raft_forward_pairs_warp(ofx_raft* r, const uint8_t* images, int n_images
         else
             st = ofx_conv2d_alpha(&d, 1.0f / std::sqrt((float)FD), s);
     }
-    if (!st) st = ofx_corr_pool_launch(ws.pyr[0], ws.pyr[1], ws.pyr[2], ws.pyr[3], B, h, w, LEVELS, s, fused_pairs);
+    if (!st) st = ofx_corr_pool_launch(ws.pyr[0], ws.pyr[1], ws.pyr[2], ws.pyr[3], B, h, w, LEVELS, s, fused_pairs || vplanes);
     if (st) return st;
     if (warped) {   // the zero-bordered RGBX copy the warp samples
         st = ofx_warp_pad_launch(warp_frame, ws.warp_pad, H, W, s);

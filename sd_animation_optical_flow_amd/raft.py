@@ -19,11 +19,13 @@ from ._lib import check
 FLAG_BGR, FLAG_SHARED_IMG2, FLAG_SHARED_IMG1, FLAG_ALT_CORR, FLAG_BF16X3, FLAG_SERIAL, FLAG_BF16X6, FLAG_BN_BATCH, FLAG_SEPARATE_STATS = 1, 2, 4, 8, 16, 32, 64, 128, 256
 CNET_NORMS = {"eval": 0, "batch": FLAG_BN_BATCH}
 PRECISIONS = {"fp32": 0, "bf16x3": FLAG_BF16X3, "bf16x6": FLAG_BF16X6}
+FLAG_VOL_BF16X3, FLAG_VOL_BF16X6 = 512, 1024
+VOLUME_PRECISIONS = {None: 0, "fp32": 0, "bf16x3": FLAG_VOL_BF16X3, "bf16x6": FLAG_VOL_BF16X6}
 
 
 class RaftEngine:
     def __init__(self, state_dict: Dict[str, torch.Tensor], device: Optional[torch.device] = None, precision: str = "fp32",
-                 cnet_norm: str = "eval"):
+                 cnet_norm: str = "eval", volume_precision: Optional[str] = None):
         """NOTE THE DEFAULT SPLIT: `RaftEngine` (and the `pdcnet_of` surface built on it) defaults to cnet_norm='eval'; `ofgen.RAFT_2`
         -- the reference's RAFT wrapper AS WRITTEN -- passes cnet_norm='batch'.  The two networks differ by more than 1 px of flow:
         build the engine with cnet_norm='batch' to mirror `RAFT_2`.
@@ -36,7 +38,13 @@ class RaftEngine:
         precision: 'fp32' (default; exact fp32 matrix-core arithmetic, the reference's), 'bf16x3' (opt-in fast
         mode: operands split into two bf16 values, three bf16 MFMAs per product, fp32 accumulate; flow EPE
         ~1e-4 px against the fp32 path) or 'bf16x6' (opt-in: three bf16 pieces = the fp32 value exactly, six
-        products, fp32 accumulate: fp32-level accuracy on the bf16 matrix cores)."""
+        products, fp32 accumulate: fp32-level accuracy on the bf16 matrix cores).
+        volume_precision: None / 'fp32' (default), 'bf16x3' or 'bf16x6' -- the arithmetic of the all-pairs correlation volume ALONE
+        (RAFT/core/corr.py:52-60), every convolution stays exact fp32: the GEMM runs on the bf16 matrix cores from operands pre-split
+        into bf16 planes (csrc/corr_split.hip; needs H % 64 == 0 and W % 128 == 0, other shapes silently take the fp32 GEMM)."""
+        if volume_precision not in VOLUME_PRECISIONS:
+            raise ValueError("volume_precision must be None, 'fp32', 'bf16x3' or 'bf16x6'")
+        self.volume_precision = volume_precision
         if precision not in PRECISIONS:
             raise ValueError(f"precision must be one of {sorted(PRECISIONS)}")
         if cnet_norm not in CNET_NORMS:
@@ -131,6 +139,7 @@ class RaftEngine:
             if t.dtype != torch.uint8:
                 raise RuntimeError(f"{nm} must be uint8")
         flags = (FLAG_BGR if bgr else 0) | PRECISIONS[self.precision] | (FLAG_SERIAL if serial else 0) | CNET_NORMS[self.cnet_norm] | (FLAG_SEPARATE_STATS if separate_stats else 0)
+        flags |= VOLUME_PRECISIONS[self.volume_precision]
         sh1, sh2 = image1.dim() == 3, image2.dim() == 3
         if sh1 and sh2:
             image1, sh1 = image1[None], False
@@ -213,7 +222,7 @@ class RaftEngine:
             self._ws = torch.empty((need,), dtype=torch.uint8, device=self.device)
         flow_up = torch.empty((B, H, W, 2), dtype=torch.float32, device=self.device)
         stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-        flags = (FLAG_BGR if bgr else 0) | PRECISIONS[self.precision] | CNET_NORMS[self.cnet_norm]
+        flags = (FLAG_BGR if bgr else 0) | PRECISIONS[self.precision] | CNET_NORMS[self.cnet_norm] | VOLUME_PRECISIONS[self.volume_precision]
         if warp_frame is None:
             check(L.ofx_raft_forward_pairs(self._h, C.c_void_p(imgs.data_ptr()), n, a1, a2, B, H, W, int(iters), flags,
                                            C.c_void_p(flow_up.data_ptr()), None,

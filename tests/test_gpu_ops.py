@@ -396,6 +396,60 @@ def test_corr_volume_pyramid_and_lookup(cuda, shape):
         assert err < 1e-4, (amp, err)
 
 
+@pytest.mark.parametrize("shape", [(3, 8, 16), (2, 16, 32), (5, 24, 16), (2, 32, 48), (3, 96, 64)])
+@pytest.mark.parametrize("precision", ["bf16x6", "bf16x3"])
+@pytest.mark.parametrize("shared", [False, True])
+def test_corr_volume_split_against_float64_and_the_fp32_volume(cuda, shape, precision, shared):
+    """`ofx_corr_volume_split` (csrc/corr_split.hip): the CorrBlock pyramid (RAFT/core/corr.py:13-27,52-60) with the volume GEMM on the
+    bf16 matrix cores from operands pre-split into bf16 planes -- the A-stationary kernel, LDS-DMA column stream, quad-ordered columns,
+    staged whole-line stores.  Every level against a float64 product of the same feature maps: the three-plane form must be as close
+    to it as the exact-fp32 GEMM is (it IS an fp32-accurate product), the two-plane form inside 2^-15 of the row scale.  Shapes:
+    N = 128 (one row group, two of its four waves past the map), N = 512, a row group that is not whole (N = 384), 1536, and the bench
+    geometry; per-pair key frames and one shared key frame (zero batch stride); feature maps with a long-tailed channel scale so the
+    low planes carry weight.  Padding-free levels: the blocked slices hold nothing but the values."""
+    ops = _ops()
+    B, h, w = shape
+    g = torch.Generator().manual_seed(11)
+    chs = torch.exp(torch.randn((1, 256, 1, 1), generator=g))
+    f1 = torch.randn((B, 256, h, w), generator=g) * chs
+    f2 = torch.randn((1 if shared else B, 256, h, w), generator=g) * chs
+    f2e = f2.expand(B, 256, h, w).contiguous()
+    ref = RO.corr_pyramid(f1.double(), f2e.double())
+    p32 = ops.corr_volume(nhwc(f1), nhwc(f2e))
+    pyr = ops.corr_volume_split(nhwc(f1), nhwc(f2), 4, precision)
+    scale = ref[0].abs().max().item()
+    for l in range(4):
+        hl, wl = h >> l, w >> l
+        assert tuple(pyr[l].shape) == (B * h * w, ops.corr_slice_floats(hl, wl))
+        got = ops.corr_unblock(pyr[l], hl, wl).cpu().double()
+        g32 = ops.corr_unblock(p32[l], hl, wl).cpu().double()
+        err = (got - ref[l][:, 0]).abs().max().item()
+        e32 = (g32 - ref[l][:, 0]).abs().max().item()
+        if precision == "bf16x6":
+            assert err <= 2.0 * e32 + 1e-7 * scale, (l, err, e32)
+        else:
+            assert err <= 3.1e-5 * scale, (l, err, scale)
+            assert l > 0 or err > e32                                       # two planes: not the fp32 GEMM by accident
+    # the lookup reads the split pyramid like any other
+    coords = RO.coords_grid(B, h, w) + (torch.rand((B, 2, h, w), generator=g) - 0.5) * 6.6
+    out = ops.corr_lookup(pyr, nhwc(coords), B, h, w)
+    refl = RO.corr_lookup([r.float() for r in ref], coords)
+    assert (nchw(out) - refl).abs().max().item() < (2e-4 if precision == "bf16x6" else 1e-3) * max(1.0, scale / 16)
+
+
+def test_corr_volume_split_preconditions(cuda):
+    """Shapes the split form does not take are refused with OFX_EINVAL (the caller falls back to `ofx_corr_volume`): level 1 must be
+    whole blocks (h % 8, w % 16), D = 256."""
+    ops = _ops()
+    for shape in ((1, 17, 16, 256), (1, 8, 24, 256), (1, 8, 16, 128)):
+        f = torch.zeros(shape, device="cuda")
+        with pytest.raises(RuntimeError):
+            ops.corr_volume_split(f, f, 4, "bf16x6")
+    f = torch.zeros((1, 8, 16, 256), device="cuda")
+    with pytest.raises(ValueError):
+        ops.corr_volume_split(f, f, 4, "fp16")
+
+
 @pytest.mark.parametrize("shape", [(4, 16, 24), (5, 12, 9), (4, 17, 10), (6, 96, 64), (2, 17, 10)])
 @pytest.mark.parametrize("sign", [1.0, -1.0])
 def test_upsample_flow_with_the_warp_inside_is_the_two_kernels_bit_for_bit(cuda, shape, sign):

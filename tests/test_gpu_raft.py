@@ -410,6 +410,56 @@ def test_split_modes_at_the_bench_size_against_the_oracles(raft_sd):
         assert e3 > 1e-6                                                      # not the fp32 path by accident
 
 
+def test_volume_precision_at_the_bench_size_against_the_oracles(raft_sd):
+    """`RaftEngine(volume_precision=...)`: ONLY the correlation volume on the bf16 matrix cores (csrc/corr_split.hip), every convolution
+    exact fp32 -- on BASELINE configs[2] through `bench.make_step`, frames {0, 63} against the oracles: the three-plane form no further
+    from the float64 network than 1.5x what the fp32 CPU oracle is (+ 2e-5 px), the two-plane form inside the 1e-3 px bar; both
+    different from the fp32 engine's flow (the option took effect), warp and mask shapes intact."""
+    import bench
+    from sd_animation_optical_flow_amd.raft import RaftEngine
+    B, H, W = 64, bench.H, bench.W
+    frames, key, key_ai, conf = bench.make_clip(B, H, W, torch.device("cuda"))
+    flows = {}
+    for mode in (None, "bf16x6", "bf16x3"):
+        eng = RaftEngine(raft_sd, volume_precision=mode)
+        flow, warped, mask = bench.make_step(eng, frames, key, key_ai, conf)()
+        assert tuple(flow.shape) == (B, H, W, 2) and torch.isfinite(flow).all()
+        assert tuple(warped.shape) == (B, H, W, 3) and tuple(mask.shape) == (B, H, W)
+        flows[mode] = flow[[0, 63]].cpu()
+        del eng, flow, warped, mask
+    assert not torch.equal(flows["bf16x6"], flows[None]) and not torch.equal(flows["bf16x3"], flows[None])
+    assert not torch.equal(flows["bf16x6"], flows["bf16x3"])
+    sd64 = RO.to_float64(raft_sd)
+    kf = key.cpu().permute(2, 0, 1)[None].float()
+    for k, b in enumerate((0, 63)):
+        a = frames[b].cpu().permute(2, 0, 1)[None].float()
+        _, up32 = RO.raft_forward(raft_sd, a, kf, iters=bench.ITERS)
+        _, up64 = RO.raft_forward(sd64, a.double(), kf.double(), iters=bench.ITERS)
+        r32, r64 = up32[0].permute(1, 2, 0), up64[0].permute(1, 2, 0)
+        e_cpu = _epe(r32.double(), r64)
+        e6 = _epe(flows["bf16x6"][k].double(), r64)
+        e0 = _epe(flows[None][k].double(), r64)
+        e3 = _epe(flows["bf16x3"][k], r32)
+        print(f"pair {b}: volume bf16x6 vs f64 {e6:.3e} px (fp32 engine {e0:.3e}, fp32 CPU oracle {e_cpu:.3e}), volume bf16x3 vs fp32 oracle {e3:.3e} px")
+        assert e6 <= 1.5 * e_cpu + 2e-5, (b, e6, e_cpu)
+        assert e3 < 1e-3, (b, e3)
+
+
+def test_volume_precision_in_the_pair_list_executor(cuda, raft_sd):
+    """The indexed-pairs executor (`forward_pairs`: KeyframeConv's ordered pairs, ofgen_keyframe_inpaint.py:627-668) with the split
+    volume: one launch over the device-side pair list, every image split once per role.  Against the fp32 executor on the same pairs."""
+    from sd_animation_optical_flow_amd.raft import RaftEngine
+    g = torch.Generator().manual_seed(8)
+    imgs = torch.randint(0, 256, (4, 128, 256, 3), generator=g, dtype=torch.uint8).cuda()
+    i1, i2 = [0, 1, 2, 3, 0], [1, 0, 3, 1, 3]
+    ref = RaftEngine(raft_sd).forward_pairs(imgs, i1, i2, iters=8)
+    for mode, tol in (("bf16x6", 2e-4), ("bf16x3", 2e-3)):
+        got = RaftEngine(raft_sd, volume_precision=mode).forward_pairs(imgs, i1, i2, iters=8)
+        e = _epe(got.cpu(), ref.cpu())
+        print(mode, "pair-list flow EPE vs fp32 executor", e)
+        assert e < tol and not torch.equal(got, ref), (mode, e)
+
+
 def _degenerate_frames(kind, B, H, W, seed=3):
     g = torch.Generator().manual_seed(seed)
     if kind == "constant":                       # zero variance everywhere but at the zero-padded borders
