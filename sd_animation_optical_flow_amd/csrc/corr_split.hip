@@ -143,41 +143,41 @@ __device__ __forceinline__ void dma1(const char* sbase, unsigned voff, unsigned 
         : "memory");
 }
 
-template <int NP, bool DB, int SAUX>
+template <int NP, int RB, bool DB, int SAUX>
 __global__ __launch_bounds__(256, 1) void corr_vol_split_kernel(const VolArgs a) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     constexpr int STAGE = kKS * NP * 1024;       // one column block of the streamed operand
     constexpr int WSH = STAGE / 4;               // the share of it one wave fetches
-    constexpr int STG = 2 * STAGE;               // behind the two stages: 16 KB of output staging per wave (level 0 | level 1)
+    constexpr int STG = 2 * STAGE;               // behind the two stages: output staging per wave (level 0 | level 1)
+    constexpr int SLV = RB * 4096;               // bytes of one staging level: the wave's RB * 32 rows x 128 B
+    static_assert(RB == 2 || (RB == 3 && !DB), "row blocks per wave: 2, or 3 with a single accumulator set");
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     int task = blockIdx.x;
     if (a.swz) task = (task & 7) * (a.ntask >> 3) + (task >> 3);    // block b runs on XCD b % 8: an XCD walks consecutive tasks
     const int z = task / a.G, g = task - z * a.G;
-    const int row0 = g * 256 + wave * 64;
-    const bool active = row0 < a.N;
+    const int row0 = g * (RB * 128) + wave * (RB * 32);
     const char* abase = a.ap + (a.ia ? (long)a.ia[z] * a.img_bytes : (long)z * a.a_zs);
     const char* bbase = a.bp + (a.ib ? (long)a.ib[z] * a.img_bytes : (long)z * a.b_zs);
     typedef __attribute__((address_space(3))) char* lds_p;
     const unsigned lds0 = (unsigned)(size_t)(lds_p)lds;
 
-    // ---- the stationary operand: 64 rows x K = 256 x NP planes
-    bf16x8 A[2][kKS][NP];
-    if (active) {
+    // ---- the stationary operand: RB * 32 rows x K = 256 x NP planes.  Row blocks past the map (a last, partial row group) hold
+    // zeros and their stores are dropped; the wave still takes part in the fetches and barriers
+    bf16x8 A[RB][kKS][NP];
+    int rbkill[RB];
+    {
         const char* src = abase + (long)(row0 >> 5) * STAGE + lane * 16;
 #pragma unroll
-        for (int rb = 0; rb < 2; ++rb)
+        for (int rb = 0; rb < RB; ++rb) {
+            const bool in = row0 + rb * 32 < a.N;        // wave-uniform
+            rbkill[rb] = in ? 0 : (int)0x80000000;
 #pragma unroll
             for (int ks = 0; ks < kKS; ++ks)
 #pragma unroll
-                for (int p = 0; p < NP; ++p) A[rb][ks][p] = *reinterpret_cast<const bf16x8*>(src + ((rb * kKS + ks) * NP + p) * 1024);
-    } else {
-#pragma unroll
-        for (int rb = 0; rb < 2; ++rb)
-#pragma unroll
-            for (int ks = 0; ks < kKS; ++ks)
-#pragma unroll
-                for (int p = 0; p < NP; ++p) A[rb][ks][p] = bf16x8{};
+                for (int p = 0; p < NP; ++p)
+                    A[rb][ks][p] = in ? *reinterpret_cast<const bf16x8*>(src + ((rb * kKS + ks) * NP + p) * 1024) : bf16x8{};
+        }
     }
 
     // ---- the way out.  The tile comes out of the MFMAs transposed: lane (m = lane & 31, hl = lane >> 5) holds, for row m of a row
@@ -193,27 +193,34 @@ __global__ __launch_bounds__(256, 1) void corr_vol_split_kernel(const VolArgs a)
     const __amdgpu_buffer_rsrc_t rs1 =
         __builtin_amdgcn_make_buffer_rsrc((void*)(a.l1 + (long)z * a.l1_zs), (short)0, (int)((long)a.N * a.slice1 * 4), 0x00020000);
     const int m = lane & 31, hl = lane >> 5, rr = lane >> 3, cc = lane & 7;
-    char* const stg = lds + STG + wave * 16384;
+    char* const stg = lds + STG + wave * (2 * SLV);
     // staging write: row m, chunk (2q + hl) ^ (m & 7) = the q = 0 address with bits 5, 6 flipped by q
     const int sw0 = m * 128 + ((hl ^ (m & 7)) << 4);
     // level-1 staging write: row m, chunk ((2 sy + py) * 2 + sx) ^ (m & 7), 8 bytes at 8 hl
-    const int sw1 = 8192 + m * 128 + ((m & 7) << 4) + 8 * hl;
+    const int sw1 = SLV + m * 128 + ((m & 7) << 4) + 8 * hl;
     // staging read: row rr + 8k (k = 0..3), chunk cc: eight lanes cover a row
     const int sr = rr * 128 + ((cc ^ rr) << 4);
     const int rowr = row0 + rr;
-    const int vg0 = (active && !(a.dbg & 1)) ? (rowr * a.N + cc * 4) * 4 : kOOB;
-    const int vg1 = (active && !(a.dbg & 5)) ? (rowr * a.slice1 + cc * 4) * 4 : kOOB;
+    const int vg0 = !(a.dbg & 1) ? (rowr * a.N + cc * 4) * 4 : kOOB;
+    const int vg1 = !(a.dbg & 5) ? (rowr * a.slice1 + cc * 4) * 4 : kOOB;
     const int step0 = 8 * a.N * 4, step1 = 8 * a.slice1 * 4;      // eight rows down, bytes
 
-    // park a finished tile (sub = its place in the quad): pieces e = 0..7 level 0, e = 8..11 the 2x2 averages
-    auto park = [&](const f32x16 (&acc)[2], int e, int sub) __attribute__((always_inline)) {
-        if (e < 8) {
+    // k-step at which piece e of a parked tile is read back (it is stored one k-step later): the way out is paced over the whole block
+    static constexpr auto rd_step = [](int e) constexpr {
+        if (RB == 3) return (e * 5) / 4;                        // 12 pieces: 0 1 2 3 5 6 7 8 10 11 12 13
+        const int r = (DB ? 1 : 0) + 2 * e;                     // 8 pieces: every second k-step (two-set form: after the park)
+        return r < 14 ? r : 14;
+    };
+    // park a finished tile (sub = its place in the quad): pieces e = 0 .. 4 RB - 1 level 0, then 2 RB pieces of 2x2 averages
+    constexpr int NP0 = 4 * RB, NPK = 6 * RB;
+    auto park = [&](const f32x16 (&acc)[RB], int e, int sub) __attribute__((always_inline)) {
+        if (e < NP0) {
             const int rb = e >> 2, q = e & 3;
             f4v t = {acc[rb][4 * q + 0], acc[rb][4 * q + 1], acc[rb][4 * q + 2], acc[rb][4 * q + 3]};
             *reinterpret_cast<f4v*>(stg + rb * 4096 + (sw0 ^ (q << 5))) = t;
         } else {
             // registers 4q + c: block row q, block column 4hl + c.  2x2 average: rows (2py, 2py + 1), columns (2c', 2c' + 1)
-            const int rb = (e - 8) >> 1, py = (e - 8) & 1, u = 8 * py;
+            const int rb = (e - NP0) >> 1, py = (e - NP0) & 1, u = 8 * py;
             const int chunk = ((2 * (sub >> 1) + py) << 1) + (sub & 1);
             f2v t;
             t[0] = ((acc[rb][u + 0] + acc[rb][u + 1]) + (acc[rb][u + 4] + acc[rb][u + 5])) * 0.25f;
@@ -221,13 +228,13 @@ __global__ __launch_bounds__(256, 1) void corr_vol_split_kernel(const VolArgs a)
             *reinterpret_cast<f2v*>(stg + rb * 4096 + (sw1 ^ (chunk << 4))) = t;
         }
     };
-    // read piece e (0..7: row block e >> 2, rows 8 (e & 3) ..) of a staging area back / store it as whole lines
+    // read piece e (row block e >> 2, rows 8 (e & 3) ..) of a staging area back / store it as whole lines
     auto unpark = [&](int e, int lvl) __attribute__((always_inline)) -> v4i {
-        return *reinterpret_cast<const v4i*>(stg + lvl * 8192 + (e >> 2) * 4096 + (e & 3) * 1024 + sr);
+        return *reinterpret_cast<const v4i*>(stg + lvl * SLV + (e >> 2) * 4096 + (e & 3) * 1024 + sr);
     };
     auto send = [&](v4i t, int e, int lvl, int so, int kill) __attribute__((always_inline)) {
-        if (lvl == 0) __builtin_amdgcn_raw_buffer_store_b128(t, rs0, vg0 | kill, so + e * step0, SAUX);
-        else __builtin_amdgcn_raw_buffer_store_b128(t, rs1, vg1 | kill, so + e * step1, SAUX);
+        if (lvl == 0) __builtin_amdgcn_raw_buffer_store_b128(t, rs0, vg0 | kill | rbkill[e >> 2], so + e * step0, SAUX);
+        else __builtin_amdgcn_raw_buffer_store_b128(t, rs1, vg1 | kill | rbkill[e >> 2], so + e * step1, SAUX);
     };
 
     // ---- the stream
@@ -254,7 +261,7 @@ __global__ __launch_bounds__(256, 1) void corr_vol_split_kernel(const VolArgs a)
     // One column block: 16 k-steps of NP fragment reads (issued a k-step ahead) and 4 * NP MFMAs into `acc`.  Spread over the first
     // k-steps: (DB) the previous tile `prev` (place PS in its quad) is parked; its level-0 lines are read back and stored at so0; when
     // it closed a quad (PS == 3) the quad's level-1 lines follow at so1.  kill = kOOB: there is no previous tile.
-    auto compute = [&](f32x16 (&acc)[2], const f32x16 (&prev)[2], int stage, int CS, int PS, int so0, int so1, int kill, bool more,
+    auto compute = [&](f32x16 (&acc)[RB], const f32x16 (&prev)[RB], int stage, int CS, int PS, int so0, int so1, int kill, bool more,
                        const char* ng, unsigned nl) __attribute__((always_inline)) {
         const char* s = lds + stage * STAGE + lane * 16;
         bf16x8 B[2][NP];
@@ -264,8 +271,7 @@ __global__ __launch_bounds__(256, 1) void corr_vol_split_kernel(const VolArgs a)
         // the way out is paced: HBM takes a column block's 40 KB per CU no faster than the MFMAs produce it, and a store that cannot
         // issue holds up the MFMAs behind it (one wave per SIMD issues in order) -- so one read-back / store per two k-steps, spread over
         // the whole block, not a burst behind the park
-        constexpr int R0 = DB ? 1 : 0;
-        auto rd_at = [](int e) { return (R0 + 2 * e) < 14 ? (R0 + 2 * e) : 14; };
+        auto rd_at = [](int e) { return rd_step(e); };
 #pragma unroll
         for (int ks = 0; ks < kKS; ++ks) {
             const int c = ks & 1;
@@ -290,27 +296,26 @@ __global__ __launch_bounds__(256, 1) void corr_vol_split_kernel(const VolArgs a)
             // form's tile in two halves, each under the other row block's MFMAs of the first / last k-step, measured SLOWER -- 5.8 against
             // 5.65 ms: six back-to-back MFMAs on one accumulator cost more than the park they cover.)
 #pragma unroll
-            for (int i = 0; i < NPROD; ++i) {
-                prod(0, i);
-                prod(1, i);
-            }
+            for (int i = 0; i < NPROD; ++i)
+#pragma unroll
+                for (int rb = 0; rb < RB; ++rb) prod(rb, i);
             if constexpr (DB) {
-                if (ks < 2) {     // park row block ks of the previous tile
+                if (ks < RB) {    // park row block ks of the previous tile
 #pragma unroll
                     for (int q = 0; q < 4; ++q) park(prev, 4 * ks + q, PS);
-                    park(prev, 8 + 2 * ks, PS);
-                    park(prev, 9 + 2 * ks, PS);
+                    park(prev, NP0 + 2 * ks, PS);
+                    park(prev, NP0 + 1 + 2 * ks, PS);
                 }
             }
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
+            for (int e = 0; e < NP0; ++e) {
                 if (ks == rd_at(e) + 1) {
                     send(hold[0], e, 0, so0, kill);
                     if (PS == 3) send(hold[1], e, 1, so1, kill);
                 }
             }
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
+            for (int e = 0; e < NP0; ++e) {
                 if (ks == rd_at(e)) {
                     hold[0] = unpark(e, 0);
                     if (PS == 3) hold[1] = unpark(e, 1);
@@ -338,9 +343,9 @@ __global__ __launch_bounds__(256, 1) void corr_vol_split_kernel(const VolArgs a)
         for (int i = 0; i < (task & 15); ++i) __builtin_amdgcn_s_sleep(3);
     }
     fetch(tq0 * 4, 0);
-    f32x16 acc0[2], acc1[2];
+    f32x16 acc0[RB], acc1[RB];
 #pragma unroll
-    for (int rb = 0; rb < 2; ++rb)
+    for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc0[rb][e] = acc1[rb][e] = 0.0f;
     int p0 = 0, p1 = 0, c0 = 0, c1 = 0;     // offsets of the tile on its way out / of the current tile
@@ -349,10 +354,9 @@ __global__ __launch_bounds__(256, 1) void corr_vol_split_kernel(const VolArgs a)
     // while the stores stay in flight under the next block's MFMAs (vmcnt(0) here serialises the write stream with the arithmetic).
     // level-0 stores of a block behind its last fetch piece (the piece goes out at the head of k-step NPIECE - 1, store e at the end
     // of k-step min(R0 + 2e, 14) + 1)
-    constexpr int kR0 = DB ? 1 : 0;
     constexpr int kBehind = [] {
         int n = 0;
-        for (int e = 0; e < 8; ++e) n += ((kR0 + 2 * e < 14 ? kR0 + 2 * e : 14) + 1 >= NPIECE - 1) ? 1 : 0;
+        for (int e = 0; e < NP0; ++e) n += (rd_step(e) + 1 >= NPIECE - 1) ? 1 : 0;
         return n;
     }();
     auto block = [&](auto sub_tag, int t, int tn, bool first, bool last) __attribute__((always_inline)) {
@@ -374,7 +378,7 @@ __global__ __launch_bounds__(256, 1) void corr_vol_split_kernel(const VolArgs a)
         } else {
             compute(acc0, acc0, SUB & 1, SUB, PS, p0, p1, kill, more, ng, nl);
 #pragma unroll
-            for (int e = 0; e < 12; ++e) park(acc0, e, SUB);
+            for (int e = 0; e < NPK; ++e) park(acc0, e, SUB);
         }
         p0 = c0; p1 = c1;
     };
@@ -392,41 +396,38 @@ __global__ __launch_bounds__(256, 1) void corr_vol_split_kernel(const VolArgs a)
     // the last tile (it closes a quad)
     if constexpr (DB) {
 #pragma unroll
-        for (int e = 0; e < 12; ++e) park(acc1, e, 3);
+        for (int e = 0; e < NPK; ++e) park(acc1, e, 3);
     }
 #pragma unroll
     for (int lvl = 0; lvl < 2; ++lvl)
 #pragma unroll
-        for (int e = 0; e < 8; ++e) send(unpark(e, lvl), e, lvl, lvl ? p1 : p0, 0);
+        for (int e = 0; e < NP0; ++e) send(unpark(e, lvl), e, lvl, lvl ? p1 : p0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no LDS-DMA piece may still be on its way when the workgroup's LDS is handed on
 }
 
 template <int NP>
-int launch_vol(const VolArgs& a, hipStream_t s) {
-    // bf16x6 keeps 384 registers of operand: one accumulator set, the tile is parked behind its last MFMA; bf16x3 has room for two
-    static const char* v = getenv("OFX_VOLSPLIT_VARIANT");   // diagnostic: "db" / "nodb"
-    const bool db = v ? (v[0] == 'd') : NP == 2;
-    const size_t ldsb = 2 * kKS * NP * 1024 + 4 * 16384;
+int launch_vol(VolArgs a, hipStream_t s) {
+    // Row blocks per wave and accumulator sets.  bf16x6 keeps 384 registers of operand for 64 rows: one accumulator set, the tile is
+    // parked behind its last MFMA.  bf16x3 has the registers either for two sets on 64 rows or for 96 rows with one set: 96 rows win
+    // (4.5 MFMAs per fragment read instead of 3, a third fewer column-stream bytes and barriers) wherever 384-row groups tile the map.
+    static const char* v = getenv("OFX_VOLSPLIT_VARIANT");   // diagnostic: "db" / "nodb" (64 rows), "r3" (96 rows)
+    const int rb = NP == 2 && (v ? v[0] == 'r' : a.N % 384 == 0) ? 3 : 2;
+    const bool db = NP == 2 && rb == 2 && (v ? v[0] == 'd' : true);
+    a.G = (a.N + rb * 128 - 1) / (rb * 128);
+    a.ntask = a.nz * a.G;
+    a.swz = (a.ntask % 8 == 0) ? 1 : 0;
+    const size_t ldsb = 2 * kKS * NP * 1024 + 4 * rb * 8192;
     auto go = [&](auto kern) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb);
         hipLaunchKernelGGL(kern, dim3((unsigned)a.ntask), dim3(256), ldsb, s, a);
     };
-    static const char* ax = getenv("OFX_VOLSPLIT_AUX");
-    const int aux = ax ? atoi(ax) : 0;
     if constexpr (NP == 2) {
-        if (aux == 2) go(corr_vol_split_kernel<NP, true, 2>);
-        else if (aux == 1) go(corr_vol_split_kernel<NP, true, 1>);
-        else if (aux == 16) go(corr_vol_split_kernel<NP, true, 16>);
-        else if (aux == 17) go(corr_vol_split_kernel<NP, true, 17>);
-        else if (db) go(corr_vol_split_kernel<NP, true, 0>);
-        else go(corr_vol_split_kernel<NP, false, 0>);
+        if (rb == 3) go(corr_vol_split_kernel<NP, 3, false, 0>);
+        else if (db) go(corr_vol_split_kernel<NP, 2, true, 0>);
+        else go(corr_vol_split_kernel<NP, 2, false, 0>);
     } else {
         (void)db;
-        if (aux == 2) go(corr_vol_split_kernel<NP, false, 2>);
-        else if (aux == 1) go(corr_vol_split_kernel<NP, false, 1>);
-        else if (aux == 16) go(corr_vol_split_kernel<NP, false, 16>);
-        else if (aux == 17) go(corr_vol_split_kernel<NP, false, 17>);
-        else go(corr_vol_split_kernel<NP, false, 0>);
+        go(corr_vol_split_kernel<NP, 2, false, 0>);
     }
     return ofx_launch_status();
 }
@@ -459,11 +460,10 @@ int ofx_corr_vol_split_launch(const void* ap, const void* bp, const int* ia, con
     OFX_REQUIRE(ap && bp && l0 && l1 && nz > 0 && (planes == 2 || planes == 3) && ofx_corr_volsplit_ok(h, w, 256), OFX_EINVAL);
     VolArgs a{};
     a.ap = (const char*)ap; a.bp = (const char*)bp; a.ia = ia; a.ib = ib; a.a_zs = a_zs; a.b_zs = b_zs;
-    a.N = h * w; a.T = a.N / 32; a.G = (a.N + 255) / 256; a.nz = nz; a.ntask = nz * a.G;
+    a.N = h * w; a.T = a.N / 32; a.nz = nz;
     a.img_bytes = (long)ofx_corr_planes_bytes(h, w, planes);
     a.wb0 = w / 8; a.wb1 = w / 16; a.slice1 = ofx_corr_slice_floats_l(h >> 1, w >> 1);
     a.l0 = l0; a.l1 = l1; a.l0_zs = (long)a.N * a.N; a.l1_zs = (long)a.N * a.slice1;
-    a.swz = (a.ntask % 8 == 0) ? 1 : 0;
     static const char* stg = getenv("OFX_VOLSPLIT_STAGGER");
     a.stagger = stg ? atoi(stg) : 5;
     static const char* dbg = getenv("OFX_VOLSPLIT_DBG");
