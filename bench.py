@@ -303,6 +303,94 @@ def make_step(eng, frames, key, key_ai, conf, warp_mode="bilinear", separate_war
     return step
 
 
+def workspace_end_to_end(args, dist, dev, rank, world):
+    """`--workspace`: the rank-parallel END-TO-END mode (SURVEY 8e names a rank's decode / H2D / encode as the limit of the 8-GPU
+    scaling, and the resident-frame `value` cannot show it).  One shared PNG workspace of `world` key-frame segments x `--ws-segment`
+    frames (BASELINE configs[3] at world = 8: 8 x 64 frames of 512x768) written by rank 0; every rank then runs the product's own
+    `pipeline.ClipPipeline.run` on its share of the plan -- PNG decode -> H2D -> flow both ways + forward-backward confidence -> warp +
+    mask -> SD-inpaint inputs -> render -> D2H -> PNG encode -- between two barriers.  Reported per rank: frames, wall seconds,
+    end-to-end frames/s, host CPU-seconds per frame; for the job: total frames / MAX wall over the ranks.  Secondary keys only: `value`
+    stays the resident-frame number.  `--stub-step` swaps the compute step for CPU arithmetic (the gloo test of the rank plumbing)."""
+    import shutil
+    import tempfile
+    import numpy as np
+    from sd_animation_optical_flow_amd import clip, pipeline
+    from sd_animation_optical_flow_amd.workspace import VideoData
+    stub = args.stub_step
+    h, w = (16, 24) if stub else (H, W)
+    seg = max(2, int(args.ws_segment))
+    n_seg = max(1, world)
+    n = n_seg * seg
+    flags = [i % seg == 0 for i in range(n)]
+    root = [None]
+    if rank == 0:
+        root[0] = tempfile.mkdtemp(prefix="ofx_bench_ws_")
+        if stub:
+            rng = np.random.default_rng(3)
+            clip_frames = [rng.integers(0, 256, (h, w, 3), dtype=np.uint8) for _ in range(n)]
+        else:
+            frames, key, _, _ = make_clip(seg - 1, h, w, dev)
+            clip_frames = []
+            for sgi in range(n_seg):                              # segment: its key frame, then seg - 1 frames that move against it
+                clip_frames.append(torch.roll(key, shifts=17 * sgi, dims=1).cpu().numpy())
+                clip_frames += [f for f in torch.roll(frames, shifts=17 * sgi, dims=2).cpu().numpy()]
+            del frames, key
+        VideoData(clip_frames, (w, h), root[0])
+        del clip_frames
+    if dist is not None:
+        dist.broadcast_object_list(root, src=0)
+    try:
+        video = VideoData(None, (w, h), root[0])
+        if stub:
+            class StubPipe(pipeline.ClipPipeline):
+                def process_batch(self, key_raw, key_ai, raws, ids, key_index):
+                    return [pipeline.FramePacket(t, key_index, torch.zeros(1), torch.zeros(1), (raws[k] // 2 + key_ai // 2).to(torch.uint8),
+                                                 ((raws[k][..., 0] > 128).to(torch.uint8) * 255), {}) for k, t in enumerate(ids)]
+            pipe = StubPipe(algo=None, render=lambda pkt, raw: torch.where(pkt.mask[..., None] > 0, raw, pkt.warped), batch=4,
+                            device=torch.device("cpu"), io_threads=1, edge_batch=2)
+        else:
+            from sd_animation_optical_flow_amd import pdcnet_of
+            pipe = pipeline.ClipPipeline(pdcnet_of.PDCNetPlus("random:0", device=dev), batch=args.batch, warp_mode="bilinear", thres=0.95, ksize=7)
+        plan = clip.plan_segments(flags, world)
+        mine = sum(len(p.frames[rank]) for p in plan) + sum(1 for p in plan if p.owner == rank)
+        sync = (lambda: None) if stub else torch.cuda.synchronize
+
+        def once():
+            if dist is not None:
+                dist.barrier()
+            sync()
+            c0, t0 = time.process_time(), time.perf_counter()
+            pipe.run(video, flags)
+            sync()
+            return time.perf_counter() - t0, time.process_time() - c0
+        if not stub:
+            once()                                               # warm-up: workspaces, thread pools, pinned buffers, page cache
+        dt, cpu = once()
+        rec = {"rank": rank, "frames": mine, "wall_s": round(dt, 4), "end_to_end_fps": round(mine / dt, 2) if mine else 0.0,
+               "host_cpu_s_per_frame": round(cpu / mine, 5) if mine else None, "io_threads": pipe.io_threads}
+        recs = [rec]
+        if dist is not None:
+            recs = [None] * world
+            dist.all_gather_object(recs, rec)
+            dist.barrier()
+        if rank != 0:
+            return None
+        wall = max(r["wall_s"] for r in recs)
+        ok = all(video.generated(i) for i in range(n))
+        return {"workload": f"{n}-frame {min(h, w)}x{max(h, w)} PNG workspace shared by the ranks, {n_seg} key-frame segments x {seg} frames "
+                            f"(BASELINE configs[3] at 8 ranks), ClipPipeline.run per rank on its plan share, PNG in -> PNG out",
+                "ranks": world, "frames": n, "every_frame_written": ok, "max_wall_s": wall, "job_end_to_end_fps": round(n / wall, 2),
+                "per_rank": recs, "usable_cores": usable_cores(), "compute": "cpu stub" if stub else "hip",
+                "broadcasts": sum(1 for p in plan if p.needs_broadcast),
+                "note": "secondary: `value` times resident frames.  A curve over N exists only where the driver ran this command on N "
+                        "devices; no multi-GPU run was taken from the build sessions (one device per box)"}
+    finally:
+        if dist is not None:
+            dist.barrier()
+        if rank == 0 and root[0]:
+            shutil.rmtree(root[0], ignore_errors=True)
+
+
 def stub_step_factory(dev):
     """CPU stand-in for the hot path (hidden --stub-step): lets the world_size-2 gloo test drive every line of the
     rank plumbing (init, key-frame broadcast, barrier, timed loop, MAX all-reduce, one JSON line) without a GPU."""
@@ -341,6 +429,9 @@ def main():
     ap.add_argument("--verify-npz", default=None, help=argparse.SUPPRESS)
     ap.add_argument("--verify-only", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--stub-step", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--workspace", action="store_true", help="also run the rank-parallel END-TO-END mode: every rank runs ClipPipeline.run "
+                    "on its share of one shared PNG workspace (secondary keys under `workspace_ranks`; `value` is unchanged)")
+    ap.add_argument("--ws-segment", type=int, default=64, help="frames per key-frame segment of the --workspace mode (one segment per rank)")
     args = ap.parse_args()
     if args.cpu_baseline_only:
         print(json.dumps(cpu_baseline(verify=args.verify_npz)))
@@ -435,6 +526,9 @@ def main():
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    ws_ranks = None
+    if args.workspace:
+        ws_ranks = workspace_end_to_end(args, dist, dev, rank, world)
     if rank != 0:
         if dist is not None:
             dist.destroy_process_group()
@@ -454,6 +548,8 @@ def main():
                                f"fp32 + {args.warp_mode} warp + mask(conf<0.95, 7x7); configs[3] sharding at N>1",
                    "frames_per_gpu": B, "H": H, "W": W, "iters": ITERS, "parallelism": f"frame-parallel x{n_gpus}"},
     }
+    if ws_ranks is not None:
+        out["workspace_ranks"] = ws_ranks
     if args.stub_step:
         out["data"] = "stub step (rank-plumbing test, no GPU work)"
         if dist is not None:

@@ -353,3 +353,22 @@ def test_pipeline_run_failures_and_collective_guard(tmp_path, monkeypatch):
     monkeypatch.setattr(tdist, "get_backend", lambda group=None: "nccl")
     with pytest.raises(RuntimeError, match="RCCL broadcasts need"):
         pipe._check_collective()
+
+
+def test_bench_workspace_mode_two_ranks_gloo():
+    """`python bench.py --gpus 2 --workspace` (hidden CPU stub step, gloo): the rank-parallel END-TO-END mode -- one shared PNG
+    workspace written by rank 0, its path broadcast, every rank running the real `ClipPipeline.run` on its plan share between two
+    barriers, per-rank records gathered on rank 0.  One JSON line; `value` is still the step's number; two per-rank records whose
+    frames add up to the workspace, every AI frame on disk."""
+    import json
+    r = _run_bench(["--gpus", "2", "--steps", "2", "--warmup", "0", "--stub-step", "--workspace", "--ws-segment", "7"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.strip().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    ws = out["workspace_ranks"]
+    assert out["n_gpus"] == 2 and out["value"] > 0
+    assert ws["ranks"] == 2 and ws["frames"] == 14 and ws["every_frame_written"] and ws["compute"] == "cpu stub"
+    assert [p["rank"] for p in ws["per_rank"]] == [0, 1] and sum(p["frames"] for p in ws["per_rank"]) == 14
+    assert all(p["wall_s"] > 0 and p["end_to_end_fps"] > 0 for p in ws["per_rank"]) and ws["max_wall_s"] == max(p["wall_s"] for p in ws["per_rank"])
+    assert "no multi-GPU run" in ws["note"]
