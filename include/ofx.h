@@ -240,7 +240,9 @@ long ofx_pack_conv_weight(const float* w_oihw, int Cout, int Cin, int KH, int KW
 int ofx_split_conv_weight(const float* packed, long n_floats, float* out);
 /* The same for the three-piece arithmetic (OFX_PREC_BF16X6_W): `out` holds 1.5 * n_floats floats -- first the [hi x4 | mid x4] groups
  * (16 bytes per four consecutive k), then the [lo x4] groups (8 bytes per four k); hi + mid + lo = x exactly unless lo underflows.
- * The whole matrix [Cout][Kpad] must be converted in one call (the lo groups are addressed from its end). */
+ * The whole matrix [Cout][Kpad] must be converted in one call (the lo groups are addressed from its end): a convolution that uses it
+ * passes d->Cout = that row count and d->nz <= 1 (a row slice or a batched GEMM would read the lo groups from the wrong place;
+ * ofx_conv2d returns OFX_EINVAL for nz > 1, and for a precision outside OFX_PREC_FP32 .. OFX_PREC_BF16X6_W). */
 int ofx_split_conv_weight3(const float* packed, long n_floats, float* out);
 
 /* instance norm statistics over HW per (b,c): mean and 1/sqrt(var+eps) (biased var), NHWC input; C <= 256.

@@ -1272,6 +1272,10 @@ extern "C" int ofx_conv2d_alpha(const ofx_conv_desc* d, float alpha, void* strea
     }
     if (d->addend) OFX_REQUIRE(d->ldadd >= d->Cout, OFX_EINVAL);
     const int nz = d->nz > 1 ? d->nz : 1;
+    OFX_REQUIRE(d->precision >= OFX_PREC_FP32 && d->precision <= OFX_PREC_BF16X6_W, OFX_EINVAL);
+    // OFX_PREC_BF16X6_W: the kernel finds the lo pieces of the pre-split matrix at w + Cout * Kpad * 4 -- true only for the WHOLE matrix
+    // `ofx_split_conv_weight3` converted (Cout = its row count) of ONE problem; a batched GEMM advances w per problem
+    if (d->precision == OFX_PREC_BF16X6_W) OFX_REQUIRE(nz == 1, OFX_EINVAL);
     {
         // The epilogue addresses out / res / addend / aux_* with 32-bit byte offsets (descriptor extent
         // M * ld * 4).  A pure GEMM (1x1, stride 1, no padding, plain epilogue -- the correlation volume of a

@@ -168,10 +168,9 @@ class FrameWriter:
         if frame.dtype != torch.uint8 or frame.dim() != 3:
             raise ValueError(f"frame {index}: expected a uint8 [H,W,C] tensor, got {frame.dtype} {tuple(frame.shape)}")
         self._sem.acquire()
-        buf = None
+        buf = ev = None
         try:
             buf = self._buffer(frame)
-            ev = None
             if self.cuda and frame.is_cuda:
                 cur = torch.cuda.current_stream(self.device)
                 self._stream.wait_stream(cur)                # after the kernels that rendered the frame
@@ -196,8 +195,11 @@ class FrameWriter:
                     self._sem.release()
             fut = self.pool.submit(job)
         except BaseException:
-            # nothing was handed to a worker: give the staging slot (and the buffer, if one was taken) back
+            # nothing was handed to a worker: give the staging slot (and the buffer, if one was taken) back -- but not while the
+            # D2H copy that was already enqueued (pool.submit can fail after it) may still be writing into that buffer
             if buf is not None:
+                if ev is not None:
+                    ev.synchronize()
                 self._recycle(buf)
             self._sem.release()
             raise

@@ -20,6 +20,7 @@ from typing import Callable, Dict, List, Optional
 
 import numpy as np
 import torch
+import torch.distributed as dist
 
 from . import clip, handoff, keyframes, ops
 
@@ -110,6 +111,19 @@ class ClipPipeline:
         # network's convex upsample (one kernel), the cubic modes take upsample -> ofx_warp_and_mask
         self.synth = clip.FrameSynthesizer(algo, warp_mode=warp_mode, thres=self.thres, ksize=self.ksize, bgr=True) if algo is not None else None
 
+    def _rank_world(self):
+        """(rank, world) of THIS pipeline's process group: the plan is sized by it and owners are ranks inside it."""
+        if self.group is None or not (dist.is_available() and dist.is_initialized()):
+            return clip.dist_info()
+        r = dist.get_rank(self.group)
+        if r < 0:
+            raise RuntimeError("ClipPipeline: this process is not a member of the pipeline's process group")
+        return r, dist.get_world_size(self.group)
+
+    def _global_rank(self, group_rank: int) -> int:
+        """`src` of a collective is a GLOBAL rank; plan owners are ranks of `group`."""
+        return group_rank if self.group is None else dist.get_global_rank(self.group, group_rank)
+
     def key_frame_flags(self, video, th: float = 8.5) -> List[bool]:
         """One flag per WORKSPACE frame (flags[i] belongs to `video.get_raw_frame(i)`).  The workspace is already decimated
         (`keep_every` was applied when it was extracted, ofgen_keyframe_inpaint.py:342-368), so every frame is examined here and
@@ -144,7 +158,7 @@ class ClipPipeline:
         buffers while the current batch's kernels run, and uploaded on a copy stream.  `writer`: where rendered key frames go
         (`run` passes its asynchronous `hostio.FrameWriter`; default: synchronous `video.put_ai_frame`)."""
         from . import hostio
-        rank, world = clip.dist_info()
+        rank, world = self._rank_world()
         # this rank's load units, in the order they are consumed: (segment, 'key' | list of frame ids)
         units = []
         plans = clip.plan_segments(flags, world)
@@ -184,7 +198,7 @@ class ClipPipeline:
                         key_ai = torch.empty(shape, dtype=torch.uint8, device=self.device)
                     if seg.needs_broadcast:
                         # the one collective of the path; every rank of the group takes part, also those with no frame of this segment
-                        clip.broadcast_keyframe([key_ai], src=seg.owner, group=self.group)
+                        clip.broadcast_keyframe([key_ai], src=self._global_rank(seg.owner), group=self.group)
                     continue
                 ids = what
                 raws = loader.fetch(tickets.pop(k))
@@ -208,7 +222,7 @@ class ClipPipeline:
         COLLECTIVE: every rank of the group calls it; the other ranks wait in the broadcast while rank 0 detects (4 900 frames/s
         from host memory, DESIGN.md: a 10-minute collective timeout covers 2.9 M frames -- pass explicit `flags` to `run`, or a
         group created with a longer timeout, for anything beyond that)."""
-        rank, world = clip.dist_info()
+        rank, world = self._rank_world()
         if world == 1:
             return self.key_frame_flags(video, th)
         import torch.distributed as dist
@@ -217,7 +231,7 @@ class ClipPipeline:
         t = torch.zeros((n,), dtype=torch.uint8, device=self.device)
         if rank == 0:
             t.copy_(torch.tensor(self.key_frame_flags(video, th), dtype=torch.uint8))
-        dist.broadcast(t, src=0, group=self.group)
+        dist.broadcast(t, src=self._global_rank(0), group=self.group)
         return [bool(v) for v in t.cpu().tolist()]
 
     def run(self, video, flags: Optional[List[bool]] = None) -> List[int]:
@@ -229,7 +243,7 @@ class ClipPipeline:
         first thing it does is the broadcast of `shared_flags`); a rank that stays away leaves the others waiting for the
         group's collective timeout."""
         from . import hostio
-        if clip.dist_info()[1] > 1:
+        if self._rank_world()[1] > 1:
             self._check_collective()
         flags = flags if flags is not None else self.shared_flags(video)
         # staging slots for three batches: `put` must never wait for an encoder while the next batch's kernels are still to be enqueued

@@ -372,3 +372,43 @@ def test_bench_workspace_mode_two_ranks_gloo():
     assert [p["rank"] for p in ws["per_rank"]] == [0, 1] and sum(p["frames"] for p in ws["per_rank"]) == 14
     assert all(p["wall_s"] > 0 and p["end_to_end_fps"] > 0 for p in ws["per_rank"]) and ws["max_wall_s"] == max(p["wall_s"] for p in ws["per_rank"])
     assert "no multi-GPU run" in ws["note"]
+
+
+def _subgroup_worker(rank, world, port, ws):
+    import datetime
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=300))
+    try:
+        from sd_animation_optical_flow_amd import pipeline
+        from sd_animation_optical_flow_amd.workspace import VideoData
+        grp = dist.new_group(ranks=[1, 2])                # every rank of the default group makes this call
+        if rank in (1, 2):
+            p = _StubPipeline.make()
+            p.group = grp
+            keys = p.run(VideoData(None, (24, 16), ws))   # flags=None: the GROUP's rank 0 (global rank 1) detects and broadcasts
+            torch.save(keys, os.path.join(ws, f"keys_r{rank}.pt"))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_pipeline_on_a_subgroup_of_the_ranks(tmp_path):
+    """`ClipPipeline(group=...)` (round-5 ADVICE): rank and world come from the GROUP, plan owners are ranks of the group and are mapped
+    to global ranks for the `src` of every broadcast.  Three processes, the pipeline runs on the subgroup {1, 2} while rank 0 stays
+    out: the cut segment's key frame travels from global rank 1 or 2, the flags come from the group's rank 0 (global rank 1, whose
+    stub detector answers like a non-zero rank unless the group mapping is honoured), output byte-identical to one process."""
+    import numpy as np
+    from sd_animation_optical_flow_amd.workspace import VideoData
+    one, _ = _make_workspace(str(tmp_path / "one"))
+    # the group's rank 0 is GLOBAL rank 1: its stub detector returns the non-zero-rank answer (one key frame), so that is the plan
+    flags = [True] + [False] * 22
+    keys1 = _StubPipeline.make().run(one, flags)
+    two, _ = _make_workspace(str(tmp_path / "two"))
+    mp.spawn(_subgroup_worker, args=(3, _free_port(), str(tmp_path / "two")), nprocs=3, join=True)
+    keys = [torch.load(tmp_path / "two" / f"keys_r{r}.pt") for r in (1, 2)]
+    assert sorted(keys[0] + keys[1]) == keys1
+    a, b = VideoData(None, (24, 16), str(tmp_path / "one")), VideoData(None, (24, 16), str(tmp_path / "two"))
+    for i in range(23):
+        assert b.generated(i), i
+        assert np.array_equal(a.get_ai_frame(i), b.get_ai_frame(i)), i

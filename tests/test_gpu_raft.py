@@ -122,6 +122,24 @@ def test_alternate_corr_engine_path(engine, raft_sd):
     assert _epe(up.cpu(), up_ref) < 1e-3
 
 
+def test_alternate_corr_path_keeps_the_pad_columns_of_the_feature_rows_zero(engine):
+    """On the volume-free path the 12 pad columns of the lookup's 336-float rows are zeroed ONCE in front of the loop (the local
+    correlation writes 324 of them) and `convc1` multiplies them by zero weights every iteration -- 0 * NaN would be NaN, so nothing
+    may ever write there.  After 7 iterations on a workspace that was poisoned beforehand: columns 324.. are exactly zero, the
+    features in front of them are finite and not all zero (round-5 ADVICE)."""
+    H, W, B = 128, 128, 2
+    key, frames = _frames(9, B, H, W)
+    img2 = key[None].repeat(B, 1, 1, 1)
+    engine.forward(frames.cuda(), img2.cuda(), iters=2, alternate_corr=True)          # sizes the workspace
+    engine._ws.view(torch.float32)[: engine._ws.numel() // 4].fill_(float("nan"))     # stale contents of the worst kind
+    up = engine.forward(frames.cuda(), img2.cuda(), iters=7, alternate_corr=True)
+    assert torch.isfinite(up).all()
+    corr = engine.buffer("corr").view(-1, 336)
+    assert corr.shape[0] == B * (H // 8) * (W // 8)
+    assert torch.equal(corr[:, 324:], torch.zeros_like(corr[:, 324:]))
+    assert torch.isfinite(corr[:, :324]).all() and corr[:, :324].abs().sum() > 0
+
+
 def test_forward_pairs_encodes_each_image_once(engine, raft_sd):
     """Indexed pairs (KeyframeConv's N x N sweep): same flows as the pair-by-pair forward and the oracle."""
     H, W = 128, 160
