@@ -600,7 +600,8 @@ def main():
                 ks[label] = {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                              "frac": round(gbs / HBM_PEAK_GBS, 4), "frac_of_achievable": round(gbs / HBM_ACHIEVABLE_GBS, 4),
                              "bytes_per_launch": per, "avg_launch_ms": round(m / c, 4), "launches_per_step": c // steps}
-        hbm("igemm_corr_volume", "volume_bytes", "corr_volume_gemm")
+        vol_fam = "corr_vol_f32" if "corr_vol_f32" in kern else "igemm_corr_volume"    # the A-stationary kernel's fp32 form / the generic batched GEMM
+        hbm(vol_fam, "volume_bytes", "corr_volume_gemm")
         hbm("corr_pyramid_pool", "pool_bytes", "corr_pyramid_pool")
         work["lookup_total"] = work["lookup_bytes"] * ITERS
         hbm("corr_lookup", "lookup_total", "corr_lookup")
@@ -608,8 +609,10 @@ def main():
         hbm("warp_u8", "warp_bytes", "warp")
         hbm("upsample_warp", "upsample_warp_bytes", "upsample_warp")
         hbm("generate_mask", "mask_bytes", "mask")
-        m, c = per_launch(["igemm_corr_volume"])
+        m, c = per_launch([vol_fam])
         if c:
+            ks["corr_volume_gemm"]["kernel"] = ("corr_vol_split_kernel<fp32> (A-stationary, v_mfma_f32_32x32x2_f32, LDS-DMA column stream, staged whole-line stores)"
+                                                if vol_fam == "corr_vol_f32" else "igemm_kernel batched mode, epilogue kEpiVolPool")
             tfv = work["volume_flops"] * steps / (m * 1e-3) / 1e12
             ks["corr_volume_gemm"]["tflops"] = round(tfv, 2)
             ks["corr_volume_gemm"]["mfma_frac"] = round(tfv / MFMA_F32_PEAK_TFLOPS, 4)
@@ -652,7 +655,7 @@ def main():
         # per-layer table of the convolutions (executed TFLOP/s per layer: the short-K layers are the visible deficit)
         rows = []
         for name, v in layers.items():
-            if ":" in name and v.get("flops", 0) > 0 and name.split(":", 1)[0] in conv_names + ["igemm_corr_volume"]:
+            if ":" in name and v.get("flops", 0) > 0 and name.split(":", 1)[0] in conv_names + ["igemm_corr_volume", "corr_vol_f32"]:
                 rows.append({"layer": name.split(":", 1)[1], "calls_per_step": v["calls"] // steps,
                              "avg_ms": round(v["ms"] / v["calls"], 4), "ms_per_step": round(v["ms"] / steps, 3),
                              "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1)})

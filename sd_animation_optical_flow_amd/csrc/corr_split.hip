@@ -91,6 +91,33 @@ __global__ __launch_bounds__(256) void split_planes_kernel(const SplitArgs a) {
     }
 }
 
+// fp32 rows in the fragment order of v_mfma_f32_32x32x2_f32 (the exact-fp32 form of the same GEMM): per 32-row block 32 groups of
+// [lane][4 floats] -- lane l holds, for row l & 31, k = 8g + 4 (l >> 5) + slot, slot = 0..3: one 16-byte fragment read feeds four MFMAs,
+// MFMA `slot` multiplies the k pair (8g + slot, 8g + 4 + slot).  That is the k assignment of the generic fp32 kernel (conv.hip: a lane
+// half reads the float4 at k offset 4 (lane >> 5) of every 8-wide group), hence the same summation order and bit-identical sums.
+__global__ __launch_bounds__(256) void frag_order_f32_kernel(const SplitArgs a) {
+    __shared__ __attribute__((aligned(16))) float tile[32][260];
+    const int tid = threadIdx.x;
+    const int blk = blockIdx.x % a.nblk, img = blockIdx.x / a.nblk;
+    int by = 0, bx = 0;
+    if (a.quad) quad_block(blk, a.wb1, by, bx);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int idx = i * 256 + tid, row = idx >> 6, c4 = idx & 63;
+        const int pix = a.quad ? ((by << 2) + (row >> 3)) * a.w + (bx << 3) + (row & 7) : blk * 32 + row;
+        f4v v = __builtin_nontemporal_load(reinterpret_cast<const f4v*>(a.src + ((long)img * a.N + pix) * 256) + c4);
+        v *= a.alpha;
+        *reinterpret_cast<f4v*>(&tile[row][c4 * 4]) = v;
+    }
+    __syncthreads();
+    char* dst = a.dst + ((long)img * a.nblk + blk) * (32 * 1024);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int j = i * 256 + tid, g = j >> 6, ln = j & 63;
+        *reinterpret_cast<f4v*>(dst + (g * 64 + ln) * 16) = *reinterpret_cast<const f4v*>(&tile[ln & 31][8 * g + 4 * (ln >> 5)]);
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // the GEMM
 // ------------------------------------------------------------------------------------------
@@ -143,7 +170,7 @@ __device__ __forceinline__ void dma1(const char* sbase, unsigned voff, unsigned 
         : "memory");
 }
 
-template <int NP, int RB, bool DB, int SAUX>
+template <int NP, int RB, bool DB, bool F32>
 __global__ __launch_bounds__(256, 1) void corr_vol_split_kernel(const VolArgs a) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     constexpr int STAGE = kKS * NP * 1024;       // one column block of the streamed operand
@@ -151,6 +178,11 @@ __global__ __launch_bounds__(256, 1) void corr_vol_split_kernel(const VolArgs a)
     constexpr int STG = 2 * STAGE;               // behind the two stages: output staging per wave (level 0 | level 1)
     constexpr int SLV = RB * 4096;               // bytes of one staging level: the wave's RB * 32 rows x 128 B
     static_assert(RB == 2 || (RB == 3 && !DB), "row blocks per wave: 2, or 3 with a single accumulator set");
+    // F32: the exact-fp32 form on v_mfma_f32_32x32x2_f32 -- the same kernel, a "plane" is then a group of four k-pairs in fp32 (a
+    // column block is 32 KB like two bf16 planes: NP = 2), a fragment read feeds 4 MFMAs per row block
+    static_assert(!F32 || NP == 2, "fp32 form: two 16-byte fragments per k-step");
+    typedef typename std::conditional<F32, f4v, bf16x8>::type frag_t;
+    constexpr int SAUX = 0;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     int task = blockIdx.x;
@@ -164,7 +196,7 @@ __global__ __launch_bounds__(256, 1) void corr_vol_split_kernel(const VolArgs a)
 
     // ---- the stationary operand: RB * 32 rows x K = 256 x NP planes.  Row blocks past the map (a last, partial row group) hold
     // zeros and their stores are dropped; the wave still takes part in the fetches and barriers
-    bf16x8 A[RB][kKS][NP];
+    frag_t A[RB][kKS][NP];
     int rbkill[RB];
     {
         const char* src = abase + (long)(row0 >> 5) * STAGE + lane * 16;
@@ -176,7 +208,7 @@ __global__ __launch_bounds__(256, 1) void corr_vol_split_kernel(const VolArgs a)
             for (int ks = 0; ks < kKS; ++ks)
 #pragma unroll
                 for (int p = 0; p < NP; ++p)
-                    A[rb][ks][p] = in ? *reinterpret_cast<const bf16x8*>(src + ((rb * kKS + ks) * NP + p) * 1024) : bf16x8{};
+                    A[rb][ks][p] = in ? *reinterpret_cast<const frag_t*>(src + ((rb * kKS + ks) * NP + p) * 1024) : frag_t{};
         }
     }
 
@@ -264,9 +296,9 @@ __global__ __launch_bounds__(256, 1) void corr_vol_split_kernel(const VolArgs a)
     auto compute = [&](f32x16 (&acc)[RB], const f32x16 (&prev)[RB], int stage, int CS, int PS, int so0, int so1, int kill, bool more,
                        const char* ng, unsigned nl) __attribute__((always_inline)) {
         const char* s = lds + stage * STAGE + lane * 16;
-        bf16x8 B[2][NP];
+        frag_t B[2][NP];
 #pragma unroll
-        for (int p = 0; p < NP; ++p) B[0][p] = *reinterpret_cast<const bf16x8*>(s + p * 1024);
+        for (int p = 0; p < NP; ++p) B[0][p] = *reinterpret_cast<const frag_t*>(s + p * 1024);
         v4i hold[2];
         // the way out is paced: HBM takes a column block's 40 KB per CU no faster than the MFMAs produce it, and a store that cannot
         // issue holds up the MFMAs behind it (one wave per SIMD issues in order) -- so one read-back / store per two k-steps, spread over
@@ -278,20 +310,22 @@ __global__ __launch_bounds__(256, 1) void corr_vol_split_kernel(const VolArgs a)
             if (ks < NPIECE && more) fetch_piece(ks, ng, nl);
             if (ks + 1 < kKS) {
 #pragma unroll
-                for (int p = 0; p < NP; ++p) B[c ^ 1][p] = *reinterpret_cast<const bf16x8*>(s + ((ks + 1) * NP + p) * 1024);
+                for (int p = 0; p < NP; ++p) B[c ^ 1][p] = *reinterpret_cast<const frag_t*>(s + ((ks + 1) * NP + p) * 1024);
             }
             // products smallest first; the streamed fragment is the FIRST operand: the tile comes out transposed (rows = columns j)
             auto prod = [&](int rb, int i) __attribute__((always_inline)) {
-                constexpr int PB3[6] = {2, 1, 0, 1, 0, 0}, PA3[6] = {0, 1, 2, 0, 1, 0}, PB2[3] = {1, 0, 0}, PA2[3] = {0, 1, 0};
-                const int pb = NP == 3 ? PB3[i] : PB2[i], pa = NP == 3 ? PA3[i] : PA2[i];
-                if (ks == 0 && i == 0) {      // the first product of a tile starts from zero
-                    const f32x16 zero = {};
-                    acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(B[c][pb], A[rb][ks][pa], zero, 0, 0, 0);
+                const f32x16 zero = {};
+                const bool first = ks == 0 && i == 0;     // the first product of a tile starts from zero
+                if constexpr (F32) {
+                    // fragment i >> 2 (eight k), k pair i & 3: the summation order of the generic fp32 kernel (bit-identical results)
+                    acc[rb] = __builtin_amdgcn_mfma_f32_32x32x2f32(B[c][i >> 2][i & 3], A[rb][ks][i >> 2][i & 3], first ? zero : acc[rb], 0, 0, 0);
                 } else {
-                    acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(B[c][pb], A[rb][ks][pa], acc[rb], 0, 0, 0);
+                    constexpr int PB3[6] = {2, 1, 0, 1, 0, 0}, PA3[6] = {0, 1, 2, 0, 1, 0}, PB2[3] = {1, 0, 0}, PA2[3] = {0, 1, 0};
+                    const int pb = NP == 3 ? PB3[i] : PB2[i], pa = NP == 3 ? PA3[i] : PA2[i];
+                    acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(B[c][pb], A[rb][ks][pa], first ? zero : acc[rb], 0, 0, 0);
                 }
             };
-            constexpr int NPROD = NP == 3 ? 6 : 3;
+            constexpr int NPROD = F32 ? 8 : NP == 3 ? 6 : 3;
             // the two row blocks alternate: consecutive MFMAs never wait for each other's accumulator.  (Parking the single-accumulator
             // form's tile in two halves, each under the other row block's MFMAs of the first / last k-step, measured SLOWER -- 5.8 against
             // 5.65 ms: six back-to-back MFMAs on one accumulator cost more than the park they cover.)
@@ -405,29 +439,47 @@ __global__ __launch_bounds__(256, 1) void corr_vol_split_kernel(const VolArgs a)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no LDS-DMA piece may still be on its way when the workgroup's LDS is handed on
 }
 
-template <int NP>
-int launch_vol(VolArgs a, hipStream_t s) {
+// Row blocks per wave (2: 256-row groups, 3: 384-row groups; bf16x6 has the registers for 2 only) and how well the tasks -- one
+// workgroup per (pair, row group), one workgroup per CU at a time -- fill the 256 CUs: tasks / (rounds * 256)
+int pick_rb(int nz, long N, int planes, double* fill) {
+    auto eff = [&](int rb) {
+        const long t = (long)nz * ((N + rb * 128 - 1) / (rb * 128));
+        return (double)t / (double)(((t + 255) / 256) * 256);
+    };
+    static const char* v = getenv("OFX_VOLSPLIT_VARIANT");   // diagnostic: "db" / "nodb" (64 rows per wave), "r3" (96)
+    int rb = 2;
+    if (planes != 3 && N % 384 == 0 && (v ? v[0] == 'r' : eff(3) >= eff(2) - 0.05)) rb = 3;
+    if (fill) *fill = eff(rb);
+    return rb;
+}
+
+// planes: 1 = exact fp32, 2 = bf16x3, 3 = bf16x6
+int launch_vol(VolArgs a, int planes, hipStream_t s) {
     // Row blocks per wave and accumulator sets.  bf16x6 keeps 384 registers of operand for 64 rows: one accumulator set, the tile is
-    // parked behind its last MFMA.  bf16x3 has the registers either for two sets on 64 rows or for 96 rows with one set: 96 rows win
-    // (4.5 MFMAs per fragment read instead of 3, a third fewer column-stream bytes and barriers) wherever 384-row groups tile the map.
-    static const char* v = getenv("OFX_VOLSPLIT_VARIANT");   // diagnostic: "db" / "nodb" (64 rows), "r3" (96 rows)
-    const int rb = NP == 2 && (v ? v[0] == 'r' : a.N % 384 == 0) ? 3 : 2;
-    const bool db = NP == 2 && rb == 2 && (v ? v[0] == 'd' : true);
+    // parked behind its last MFMA.  bf16x3 and fp32 (256 registers per 64 rows) have the registers either for two sets on 64 rows or for
+    // 96 rows with one set: 96 rows win (1.5x the MFMAs per fragment read, a third fewer column-stream bytes and barriers) wherever
+    // 384-row groups tile the map.
+    static const char* v = getenv("OFX_VOLSPLIT_VARIANT");
+    const int rb = pick_rb(a.nz, a.N, planes, nullptr);
+    const bool db = planes == 2 && rb == 2 && (v ? v[0] == 'd' : true);
+    const int np = planes == 3 ? 3 : 2;
     a.G = (a.N + rb * 128 - 1) / (rb * 128);
     a.ntask = a.nz * a.G;
     a.swz = (a.ntask % 8 == 0) ? 1 : 0;
-    const size_t ldsb = 2 * kKS * NP * 1024 + 4 * rb * 8192;
+    const size_t ldsb = 2 * kKS * np * 1024 + 4 * rb * 8192;
     auto go = [&](auto kern) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb);
         hipLaunchKernelGGL(kern, dim3((unsigned)a.ntask), dim3(256), ldsb, s, a);
     };
-    if constexpr (NP == 2) {
-        if (rb == 3) go(corr_vol_split_kernel<NP, 3, false, 0>);
-        else if (db) go(corr_vol_split_kernel<NP, 2, true, 0>);
-        else go(corr_vol_split_kernel<NP, 2, false, 0>);
+    if (planes == 1) {
+        if (rb == 3) go(corr_vol_split_kernel<2, 3, false, true>);
+        else go(corr_vol_split_kernel<2, 2, false, true>);
+    } else if (planes == 2) {
+        if (rb == 3) go(corr_vol_split_kernel<2, 3, false, false>);
+        else if (db) go(corr_vol_split_kernel<2, 2, true, false>);
+        else go(corr_vol_split_kernel<2, 2, false, false>);
     } else {
-        (void)db;
-        go(corr_vol_split_kernel<NP, 2, false, 0>);
+        go(corr_vol_split_kernel<3, 2, false, false>);
     }
     return ofx_launch_status();
 }
@@ -441,23 +493,33 @@ bool ofx_corr_volsplit_ok(int h, int w, int D) {
     return D == 256 && h % 8 == 0 && w % 16 == 0 && N >= 64 && N * N * 4 < (1L << 31) - 64;
 }
 
-size_t ofx_corr_planes_bytes(int h, int w, int planes) { return (size_t)h * w / 32 * kKS * planes * 1024; }
+// A task is one workgroup on one CU for ~(rows / 128) x 0.75 ms: the kernel pays when its tasks fill the part's rounds.  A single
+// 512x768 pair is 16-24 tasks on 256 CUs (2.2 ms where the generic GEMM's 2304 tiles take 0.2): the executor keeps the generic
+// kernel for those (same bits in fp32).
+bool ofx_corr_volsplit_pays(int nz, int h, int w, int planes) {
+    double fill = 0.0;
+    pick_rb(nz, (long)h * w, planes, &fill);
+    return fill >= 0.7;
+}
+
+size_t ofx_corr_planes_bytes(int h, int w, int planes) { return (size_t)h * w / 32 * kKS * (planes == 3 ? 3 : 2) * 1024; }   // fp32 (1): 32 KB per 32 rows, like two bf16 planes
 
 int ofx_corr_split_planes(const float* src, void* dst, int n, int h, int w, int planes, int quad, float alpha, hipStream_t s) {
-    OFX_REQUIRE(src && dst && n > 0 && (planes == 2 || planes == 3) && ofx_corr_volsplit_ok(h, w, 256), OFX_EINVAL);
+    OFX_REQUIRE(src && dst && n > 0 && planes >= 1 && planes <= 3 && ofx_corr_volsplit_ok(h, w, 256), OFX_EINVAL);
     OFX_REQUIRE(ofx_aligned16(src) && ofx_aligned16(dst), OFX_EALIGN);
     SplitArgs a{};
     a.src = src; a.dst = (char*)dst; a.N = h * w; a.w = w; a.wb1 = w / 16; a.quad = quad; a.alpha = alpha; a.nblk = a.N / 32;
     OfxProfScope prof("corr_split_planes", s);
     if (planes == 3) hipLaunchKernelGGL(split_planes_kernel<3>, dim3((unsigned)(n * a.nblk)), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL(split_planes_kernel<2>, dim3((unsigned)(n * a.nblk)), dim3(256), 0, s, a);
+    else if (planes == 2) hipLaunchKernelGGL(split_planes_kernel<2>, dim3((unsigned)(n * a.nblk)), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(frag_order_f32_kernel, dim3((unsigned)(n * a.nblk)), dim3(256), 0, s, a);
     return ofx_launch_status();
 }
 
 // level 0 (blocked) and level 1 of nz pairs from pre-split planes.  ia / ib: device arrays of image indices, or null with byte strides
 int ofx_corr_vol_split_launch(const void* ap, const void* bp, const int* ia, const int* ib, long a_zs, long b_zs, float* l0, float* l1,
                               int nz, int h, int w, int planes, hipStream_t s) {
-    OFX_REQUIRE(ap && bp && l0 && l1 && nz > 0 && (planes == 2 || planes == 3) && ofx_corr_volsplit_ok(h, w, 256), OFX_EINVAL);
+    OFX_REQUIRE(ap && bp && l0 && l1 && nz > 0 && planes >= 1 && planes <= 3 && ofx_corr_volsplit_ok(h, w, 256), OFX_EINVAL);
     VolArgs a{};
     a.ap = (const char*)ap; a.bp = (const char*)bp; a.ia = ia; a.ib = ib; a.a_zs = a_zs; a.b_zs = b_zs;
     a.N = h * w; a.T = a.N / 32; a.nz = nz;
@@ -468,9 +530,9 @@ int ofx_corr_vol_split_launch(const void* ap, const void* bp, const int* ia, con
     a.stagger = stg ? atoi(stg) : 5;
     static const char* dbg = getenv("OFX_VOLSPLIT_DBG");
     a.dbg = dbg ? atoi(dbg) : 0;
-    OfxProfScope prof(planes == 3 ? "corr_vol_split6" : "corr_vol_split3", s);
-    prof.flops(2.0 * nz * (double)a.N * a.N * 256.0 * (planes == 3 ? 6 : 3));
-    return planes == 3 ? launch_vol<3>(a, s) : launch_vol<2>(a, s);
+    OfxProfScope prof(planes == 3 ? "corr_vol_split6" : planes == 2 ? "corr_vol_split3" : "corr_vol_f32", s);
+    prof.flops(2.0 * nz * (double)a.N * a.N * 256.0 * (planes == 3 ? 6 : planes == 2 ? 3 : 1));
+    return launch_vol(a, planes, s);
 }
 
 extern "C" {
@@ -478,7 +540,7 @@ extern "C" {
 int ofx_corr_volume_split(const float* f1, const float* f2, float* const* pyr, int B, int h, int w, int D, int levels, int planes,
                           int shared_f2, void* stream) {
     OFX_REQUIRE(f1 && f2 && pyr && B > 0 && h > 0 && w > 0, OFX_EINVAL);
-    OFX_REQUIRE(levels >= 2 && levels <= 4 && (planes == 2 || planes == 3), OFX_EINVAL);
+    OFX_REQUIRE(levels >= 2 && levels <= 4 && planes >= 1 && planes <= 3, OFX_EINVAL);
     OFX_REQUIRE(ofx_corr_volsplit_ok(h, w, D), OFX_EINVAL);
     for (int l = 0; l < levels; ++l) OFX_REQUIRE(pyr[l] != nullptr && ofx_aligned16(pyr[l]), OFX_EINVAL);
     OFX_REQUIRE(ofx_aligned16(f1) && ofx_aligned16(f2), OFX_EALIGN);

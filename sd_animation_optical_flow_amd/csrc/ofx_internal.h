@@ -73,6 +73,7 @@ bool ofx_corr_volpool_ok(int h, int w);
 // (planes = 2: bf16x3, 3: bf16x6; quad = 1: rows in the quad-blocked column order of the streamed operand), and the A-stationary GEMM
 // that writes level 0 (blocked) and level 1 of nz pairs.  ia / ib: device arrays of image indices per pair, or null with byte strides
 bool ofx_corr_volsplit_ok(int h, int w, int D);
+bool ofx_corr_volsplit_pays(int nz, int h, int w, int planes);   // enough (pair, row group) tasks to fill the CUs' rounds
 size_t ofx_corr_planes_bytes(int h, int w, int planes);
 int ofx_corr_split_planes(const float* src, void* dst, int n, int h, int w, int planes, int quad, float alpha, hipStream_t s);
 int ofx_corr_vol_split_launch(const void* ap, const void* bp, const int* ia, const int* ib, long a_zs, long b_zs, float* l0, float* l1,

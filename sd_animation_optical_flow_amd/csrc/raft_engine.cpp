@@ -677,12 +677,15 @@ static int run_recurrence(ofx_raft* r, const RaftWs& ws, int B, int h, int w, in
     return 0;
 }
 
-// The volume GEMM in split-bf16 form (corr_split.hip): OFX_RAFT_VOL_BF16X3 / _BF16X6 ask for it alone (every convolution stays fp32),
-// the all-layer split modes take it along.  Its operand planes live in the recurrence's scratch (corr ... mask: dead until the first
-// iteration).  0 planes = the fp32 / generic path.
-static int volume_planes(int flags, int h, int w, long n_planes_images, const RaftWs& ws, long M) {
-    const int planes = (flags & (OFX_RAFT_VOL_BF16X6 | OFX_RAFT_BF16X6)) ? 3 : (flags & (OFX_RAFT_VOL_BF16X3 | OFX_RAFT_BF16X3)) ? 2 : 0;
-    if (!planes || !ofx_corr_volsplit_ok(h, w, FD) || getenv("OFX_NO_VOLSPLIT")) return 0;
+// The volume GEMM on the A-stationary kernel (corr_split.hip).  OFX_RAFT_VOL_BF16X3 / _BF16X6 ask for its split-bf16 forms alone (every
+// convolution stays fp32), the all-layer split modes take them along.  Its operands in fragment order live in the recurrence's scratch
+// (corr ... mask: dead until the first iteration).  0 = the generic batched GEMM of conv.hip (shapes the kernel does not take).
+static int volume_planes(int flags, int h, int w, long n_planes_images, const RaftWs& ws, long M, int nz) {
+    // 1: the exact-fp32 form of the same A-stationary kernel (round 6: bit-identical to the generic batched GEMM it replaces, whole-line
+    // stores, no operand re-fetch) -- the default wherever the shape allows; OFX_VOL_GENERIC=1 keeps the generic GEMM (diagnostic)
+    const int planes = (flags & (OFX_RAFT_VOL_BF16X6 | OFX_RAFT_BF16X6)) ? 3 : (flags & (OFX_RAFT_VOL_BF16X3 | OFX_RAFT_BF16X3)) ? 2 : 1;
+    static const bool generic = getenv("OFX_VOL_GENERIC") != nullptr;
+    if ((planes == 1 && generic) || !ofx_corr_volsplit_ok(h, w, FD) || !ofx_corr_volsplit_pays(nz, h, w, planes) || getenv("OFX_NO_VOLSPLIT")) return 0;
     const size_t room = (size_t)((const char*)(ws.mask + M * 576) - (const char*)ws.corr);
     return (size_t)n_planes_images * ofx_corr_planes_bytes(h, w, planes) <= room ? planes : 0;
 }
@@ -870,7 +873,7 @@ static int raft_forward_impl(ofx_raft* r, const uint8_t* image1, const uint8_t* 
     if (st) return st;
 
     // ---- correlation
-    const int vplanes = alt ? 0 : volume_planes(flags, h, w, (long)n1 + n2, ws, M);
+    const int vplanes = alt ? 0 : volume_planes(flags, h, w, (long)n1 + n2, ws, M, B);
     if (vplanes) {
         char* pl = (char*)ws.corr;
         const long ib = (long)ofx_corr_planes_bytes(h, w, vplanes);
@@ -1003,7 +1006,7 @@ int ofx_raft_forward_pairs_warp(ofx_raft* r, const uint8_t* images, int n_images
     const long Nb = ofx_corr_slice_floats_l(h, w);
     const long slice1p = ofx_corr_slice_floats_l(h >> 1, w >> 1);
     const bool fused_pairs = ofx_corr_volpool_ok(h, w) && Nb % 128 == 0 && N * slice1p * 4 < (1L << 31) - 64;
-    const int vplanes = volume_planes(flags, h, w, 2L * n_images, ws, (long)B * N);
+    const int vplanes = volume_planes(flags, h, w, 2L * n_images, ws, (long)B * N, B);
     if (vplanes) {
         // split-bf16 volume: every image split once per role (rows scaled in pixel order / columns in quad order), ONE launch over the
         // pair list through the device-side index arrays

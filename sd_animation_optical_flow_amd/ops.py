@@ -353,16 +353,17 @@ def corr_volume(f1: torch.Tensor, f2: torch.Tensor, levels: int = 4) -> List[tor
     return pyr
 
 
-_VOLUME_PLANES = {"bf16x3": 2, "bf16x6": 3}
+_VOLUME_PLANES = {"fp32": 1, "bf16x3": 2, "bf16x6": 3}
 
 
 def corr_volume_split(f1: torch.Tensor, f2: torch.Tensor, levels: int = 4, precision: str = "bf16x6") -> List[torch.Tensor]:
     """`corr_volume` with the GEMM in split-bf16 arithmetic (`ofx_corr_volume_split`; opt-in, RAFT/core/corr.py:52-60 is fp32).
-    f1 f32 [B,h,w,256]; f2 f32 [B,h,w,256] or [1,h,w,256] (one key frame shared by the B pairs).  precision 'bf16x3' | 'bf16x6'."""
+    f1 f32 [B,h,w,256]; f2 f32 [B,h,w,256] or [1,h,w,256] (one key frame shared by the B pairs).  precision 'bf16x3' | 'bf16x6', or
+    'fp32': the same A-stationary kernel on the fp32 matrix cores -- bit-identical to `corr_volume`."""
     a = _chk(f1, "fmap1", torch.float32)
     b = _chk(f2, "fmap2", torch.float32)
     if precision not in _VOLUME_PLANES:
-        raise ValueError("precision: 'bf16x3' or 'bf16x6'")
+        raise ValueError("precision: 'fp32', 'bf16x3' or 'bf16x6'")
     B, h, w, D = a.shape
     if b.shape[0] not in (1, B) or tuple(b.shape[1:]) != (h, w, D):
         raise RuntimeError("fmap2: [B,h,w,D] or [1,h,w,D]")

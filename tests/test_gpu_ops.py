@@ -397,7 +397,7 @@ def test_corr_volume_pyramid_and_lookup(cuda, shape):
 
 
 @pytest.mark.parametrize("shape", [(3, 8, 16), (2, 16, 32), (5, 24, 16), (2, 32, 48), (3, 96, 64)])
-@pytest.mark.parametrize("precision", ["bf16x6", "bf16x3"])
+@pytest.mark.parametrize("precision", ["bf16x6", "bf16x3", "fp32"])
 @pytest.mark.parametrize("shared", [False, True])
 def test_corr_volume_split_against_float64_and_the_fp32_volume(cuda, shape, precision, shared):
     """`ofx_corr_volume_split` (csrc/corr_split.hip): the CorrBlock pyramid (RAFT/core/corr.py:13-27,52-60) with the volume GEMM on the
@@ -406,7 +406,10 @@ def test_corr_volume_split_against_float64_and_the_fp32_volume(cuda, shape, prec
     to it as the exact-fp32 GEMM is (it IS an fp32-accurate product), the two-plane form inside 2^-15 of the row scale.  Shapes:
     N = 128 (one row group, two of its four waves past the map), N = 512, a row group that is not whole (N = 384), 1536, and the bench
     geometry; per-pair key frames and one shared key frame (zero batch stride); feature maps with a long-tailed channel scale so the
-    low planes carry weight.  Padding-free levels: the blocked slices hold nothing but the values."""
+    low planes carry weight.  Padding-free levels: the blocked slices hold nothing but the values.
+    precision 'fp32': the same kernel on v_mfma_f32_32x32x2_f32 -- what the RAFT executor runs by default since round 6 -- must be the
+    generic batched GEMM of `ofx_corr_volume` BIT FOR BIT on every level (same k assignment per lane half, same summation order, the
+    2^-4 scale folded into an operand, the same (a + b) + (c + d) pooling)."""
     ops = _ops()
     B, h, w = shape
     g = torch.Generator().manual_seed(11)
@@ -425,7 +428,9 @@ def test_corr_volume_split_against_float64_and_the_fp32_volume(cuda, shape, prec
         g32 = ops.corr_unblock(p32[l], hl, wl).cpu().double()
         err = (got - ref[l][:, 0]).abs().max().item()
         e32 = (g32 - ref[l][:, 0]).abs().max().item()
-        if precision == "bf16x6":
+        if precision == "fp32":
+            assert torch.equal(pyr[l], p32[l]), (l, err, e32)
+        elif precision == "bf16x6":
             assert err <= 2.0 * e32 + 1e-7 * scale, (l, err, e32)
         else:
             assert err <= 3.1e-5 * scale, (l, err, scale)

@@ -469,7 +469,10 @@ def test_volume_precision_in_the_pair_list_executor(cuda, raft_sd):
     from sd_animation_optical_flow_amd.raft import RaftEngine
     g = torch.Generator().manual_seed(8)
     imgs = torch.randint(0, 256, (4, 128, 256, 3), generator=g, dtype=torch.uint8).cuda()
-    i1, i2 = [0, 1, 2, 3, 0], [1, 0, 3, 1, 3]
+    # 96 ordered pairs of 4 images: (pairs x 2 row groups of the 16x32 map) fill the 256 CUs' first round to 0.75 -- below that the
+    # executor keeps the generic GEMM (`ofx_corr_volsplit_pays`) and the option has no effect
+    i1 = [0, 1, 2, 3, 0, 2] * 16
+    i2 = [1, 0, 3, 1, 3, 0] * 16
     ref = RaftEngine(raft_sd).forward_pairs(imgs, i1, i2, iters=8)
     for mode, tol in (("bf16x6", 2e-4), ("bf16x3", 2e-3)):
         got = RaftEngine(raft_sd, volume_precision=mode).forward_pairs(imgs, i1, i2, iters=8)

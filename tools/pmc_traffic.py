@@ -19,10 +19,10 @@ import sys
 
 FAMILIES = [
     ("igemm_conv_all", lambda n, gy: "igemm_kernel" in n and gy <= 1),
-    ("corr_volume_gemm", lambda n, gy: "igemm_kernel" in n and gy > 1),
+    ("corr_volume_gemm", lambda n, gy: ("igemm_kernel" in n and gy > 1) or ("corr_vol_split_kernel<2" in n and ", true>" in n)),   # fp32: the generic batched GEMM / the A-stationary kernel's fp32 form
     ("corr_vol_split6", lambda n, gy: "corr_vol_split_kernel<3" in n),
-    ("corr_vol_split3", lambda n, gy: "corr_vol_split_kernel<2" in n),
-    ("corr_split_planes", lambda n, gy: "split_planes_kernel" in n),
+    ("corr_vol_split3", lambda n, gy: "corr_vol_split_kernel<2" in n and ", false>" in n),
+    ("corr_split_planes", lambda n, gy: "split_planes_kernel" in n or "frag_order_f32_kernel" in n),
     ("corr_lookup", lambda n, gy: "corr_lookup" in n),
     ("pyramid_pool", lambda n, gy: "pyramid_pool" in n),
     ("upsample_warp", lambda n, gy: "upsample_warp_kernel" in n),
