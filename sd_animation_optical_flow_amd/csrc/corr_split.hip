@@ -361,8 +361,7 @@ __global__ __launch_bounds__(256, 1) void corr_vol_split_kernel(const VolArgs a)
         }
     };
     // scalar offsets of column block t: its level-0 block (bytes into a row's slice) and its quad's level-1 line
-    // Workgroups start at different quads of the stream and wrap around: 256 CUs in lock-step would otherwise all write the same
-    // column offset of rows that lie a multiple of 8 KB apart at any moment -- one memory channel's worth of addresses
+    // (diagnostic, a.stagger > 0: workgroups start at different quads of the stream and wrap around)
     const int quads = a.T >> 2;
     const int tq0 = a.stagger ? (task * a.stagger) % quads : 0;
     int qy = tq0 / a.wb1, qx = tq0 - qy * a.wb1;
@@ -527,7 +526,11 @@ int ofx_corr_vol_split_launch(const void* ap, const void* bp, const int* ia, con
     a.wb0 = w / 8; a.wb1 = w / 16; a.slice1 = ofx_corr_slice_floats_l(h >> 1, w >> 1);
     a.l0 = l0; a.l1 = l1; a.l0_zs = (long)a.N * a.N; a.l1_zs = (long)a.N * a.slice1;
     static const char* stg = getenv("OFX_VOLSPLIT_STAGGER");
-    a.stagger = stg ? atoi(stg) : 5;
+    // 0: every workgroup starts the stream at column block 0.  Staggered starts (OFX_VOLSPLIT_STAGGER=5: tried against a suspected
+    // channel hot spot of rows that lie a multiple of 8 KB apart) changed no timing -- and cost the XCD's L2 its hit rate on the stream:
+    // with them every workgroup fetched the whole of fmap2's planes from beyond the L2 (PMC: 6.9 GB of fetches per fp32 launch,
+    // 15.2 GB in bf16x6 form, for 0.4 GB of operands)
+    a.stagger = stg ? atoi(stg) : 0;
     static const char* dbg = getenv("OFX_VOLSPLIT_DBG");
     a.dbg = dbg ? atoi(dbg) : 0;
     OfxProfScope prof(planes == 3 ? "corr_vol_split6" : planes == 2 ? "corr_vol_split3" : "corr_vol_f32", s);

@@ -1,8 +1,8 @@
 #!/bin/bash
-# Round-5 evidence pass (run through gpurun from the repo root): single-pair kernel trace, batch sweep, workspace pipeline rate,
+# Per-round evidence pass (was r05_baseline.sh) (run through gpurun from the repo root): single-pair kernel trace, batch sweep, workspace pipeline rate,
 # KeyframeConv rate.  Everything lands under gpurun_out/<tag>_*; the summaries are copied to profiles/ by hand.
 set -u
-TAG=${1:-r05}
+TAG=${1:-r06}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out
 mkdir -p $O
