@@ -830,11 +830,12 @@ def main():
                                      ("bf16x6", "split3_mode", "opt-in; three bf16 pieces per fp32 operand (exact), six products, fp32 accumulate: "
                                       "fp32-level accuracy on the bf16 matrix cores; not the headline value")):
             fast = RaftEngine(random_state_dict(0), dev, precision=mode)
+            # the SAME step as `value` (make_step: the product's FrameSynthesizer, warp inside the convex upsample), with the engine
+            # built in that mode -- what test_split_modes_at_the_bench_size_against_the_oracles holds to the oracles
+            mstep = make_step(fast, frames, key, key_ai, conf, args.warp_mode, args.separate_warp)
 
             def fstep():
-                fl = fast.forward(frames, key, iters=ITERS)
-                ops.warp_and_mask(key_ai, fl, conf, warp_mode=args.warp_mode, thres=0.95, ksize=7)
-                return fl
+                return mstep()[0]
             fl = fstep()
             epe = float((fl - ref_flow).pow(2).sum(-1).sqrt().mean())
             emax = float((fl - ref_flow).pow(2).sum(-1).sqrt().max())
@@ -846,7 +847,7 @@ def main():
             dtf = (time.perf_counter() - t1) / args.steps
             out[key_name] = {"precision": mode, "value": round(B / dtf, 3), "unit": "pairs/s", "ms_per_step": round(dtf * 1e3, 3),
                              "flow_epe_vs_fp32_px": epe, "flow_max_err_vs_fp32_px": emax, "note": note}
-            del fast
+            del fast, mstep
         del ref_flow
 
     if not args.no_pipeline and world == 1 and args.precision == "fp32":

@@ -1,23 +1,26 @@
-// The all-pairs correlation volume (RAFT/core/corr.py:13-27,52-60) in SPLIT-bf16 form: an opt-in arithmetic of the volume GEMM only
-// (`volume_precision`); every convolution of the network stays exact fp32 and so does the headline.
+// The all-pairs correlation volume (RAFT/core/corr.py:13-27,52-60) on its own kernel -- the executor's default since round 6 in exact
+// fp32 (bit-identical to the generic batched GEMM of conv.hip it replaces), and the opt-in split-bf16 arithmetics of the volume alone
+// (`volume_precision`; every convolution of the network stays exact fp32 and so does the headline).
 //
 //   corr[b, i, j] = <fmap1[b, i, :], fmap2[b, j, :]> / sqrt(256)         (corr.py:52-60)
 //   level 1       = avg_pool2d(level 0, 2, 2) over j                     (corr.py:24-26)
 //
-// fp32 operands are split once, by their own small kernel, into bf16 PLANES (hi, lo: "bf16x3" = products hh, hl, lh; hi, mid, lo:
-// "bf16x6" = hh, hm, mh, hl, lh, mm -- 3 x 8 mantissa bits, the three dropped products sit below 2^-24 relative) laid out in MFMA
-// FRAGMENT ORDER: [32-row block][k-step of 16][plane][lane][8 bf16] -- a fragment of v_mfma_f32_32x32x16_bf16 is one contiguous KB,
-// whichever side of the product it feeds.  The 1/sqrt(D) = 2^-4 scale is folded into the fmap1 planes (exact).
+// Operands arrive in MFMA FRAGMENT ORDER from a small kernel of their own: [32-row block][k-step of 16][plane][lane][16 B] -- a fragment
+// of v_mfma_f32_32x32x16_bf16 (8 bf16 per lane) or of four v_mfma_f32_32x32x2_f32 (4 floats per lane) is one contiguous KB, whichever
+// side of the product it feeds.  Split forms: fp32 -> bf16 PLANES (hi, lo: "bf16x3" = products hh, hl, lh; hi, mid, lo: "bf16x6" = hh, hm,
+// mh, hl, lh, mm -- 3 x 8 mantissa bits, the three dropped products sit below 2^-24 relative).  The 1/sqrt(D) = 2^-4 scale is folded
+// into the fmap1 side (exact).
 //
-// The GEMM is "A-stationary": K is only 256, so a wave keeps ALL of K for its 64 rows of fmap1 in registers (2 row blocks x 16 k-steps x
-// NP planes x 4 VGPRs = 384 of the 512-entry register file in bf16x6 form, one wave per SIMD) and streams the 32-column blocks of fmap2
-// past them: per column block and k-step NP fragment reads from LDS feed 4 * NP (6 / 12) MFMAs -- a quarter / a third of a fragment read
-// per MFMA where the generic 2x2 wave tile needs half of one, and no A-side traffic at all.  The four waves of a workgroup own 256 rows
-// and share the column-block stream, which arrives in LDS by LDS-DMA (global_load_lds_dwordx4: no VGPR round trip), one 16 * NP KB
-// stage ahead, one workgroup barrier per column block.  The product is formed TRANSPOSED (C^T = B A^T: the streamed fragment is the
-// MFMA's first operand), so a lane's accumulator registers hold four CONSECUTIVE columns j of one row i: 16-byte stores of the level-0
-// rows, and the 2x2 average over (j_y, j_x) is three in-lane additions -- no DPP, no LDS.  Column blocks are walked in QUAD order
-// (the four 4x8 blocks under one 4x8 block of level 1 back to back), so the pieces of a level-1 line meet in L2.
+// The GEMM is "A-stationary": K is only 256, so a wave keeps ALL of K for its 64 (96) rows of fmap1 in registers (2 - 3 row blocks x
+// 16 k-steps x 2 - 3 fragments x 4 VGPRs = 256 - 384 of the 512-entry register file, one wave per SIMD) and streams the 32-column blocks
+// of fmap2 past them: per column block and k-step 2 - 3 fragment reads from LDS feed 6 - 24 MFMAs -- a quarter to a third of a fragment
+// read per MFMA where the generic 2x2 wave tile needs half of one, and no A-side traffic at all.  The four waves of a workgroup own
+// 256 (384) rows and share the column-block stream, which arrives in LDS by LDS-DMA (global_load_lds_dwordx4: no VGPR round trip), one
+// 32 - 48 KB stage ahead, one workgroup barrier per column block.  The product is formed TRANSPOSED (C^T = B A^T: the streamed fragment is
+// the MFMA's first operand), so a lane's accumulator registers hold four CONSECUTIVE columns j of one row i and the 2x2 average over
+// (j_y, j_x) is three in-lane additions -- no DPP; the finished tile is parked in a per-wave LDS staging area and leaves as whole
+// 128-byte lines.  Column blocks are walked in QUAD order (the four 4x8 blocks under one 4x8 block of level 1 back to back), so the
+// level-1 pieces of a quad collect into whole lines too.  Measurements and the dead ends: DESIGN.md section 0, tools/experiments/README.md.
 #include "ofx_internal.h"
 
 #include <algorithm>
@@ -467,7 +470,11 @@ int launch_vol(VolArgs a, int planes, hipStream_t s) {
     a.swz = (a.ntask % 8 == 0) ? 1 : 0;
     const size_t ldsb = 2 * kKS * np * 1024 + 4 * rb * 8192;
     auto go = [&](auto kern) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb);
+        static size_t allowed = 0;      // per instantiation (a generic lambda's body is one per kernel type): > 64 KB of dynamic LDS
+        if (allowed < ldsb) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb);
+            allowed = ldsb;
+        }
         hipLaunchKernelGGL(kern, dim3((unsigned)a.ntask), dim3(256), ldsb, s, a);
     };
     if (planes == 1) {
