@@ -28,6 +28,12 @@ import numpy as np
 import torch
 
 
+def shared_pool(threads: int) -> Optional[ThreadPoolExecutor]:
+    """One worker pool for a rank's `FrameLoader` AND `FrameWriter`: 2 x `threads` workers (the two private pools it replaces had
+    `threads` each).  The caller shuts it down after both helpers are closed."""
+    return ThreadPoolExecutor(2 * int(threads), thread_name_prefix="ofx-io") if int(threads) > 0 else None
+
+
 class FrameLoader:
     """Prefetching reader of `video.get_raw_frame(i)` batches.
 
@@ -37,14 +43,17 @@ class FrameLoader:
 
     `threads=0`: no pool, no pinned memory -- `fetch` decodes inline and uploads synchronously (the round-3 behaviour)."""
 
-    def __init__(self, video, device, threads: int = 4, slots: int = 3, batch: int = 64):
+    def __init__(self, video, device, threads: int = 4, slots: int = 3, batch: int = 64, pool: Optional[ThreadPoolExecutor] = None):
+        """`pool`: a worker pool shared with a `FrameWriter` (`shared_pool`): a rank's decoders and encoders are busy at opposite ends
+        of its share, so one pool of 2 x threads halves the decode in front of the first kernel and the encode behind the last."""
         self.video, self.device = video, torch.device(device)
         self.threads = max(0, int(threads))
         self.cuda = self.device.type == "cuda"
         H, W = video.size_hw
         self.shape = (H, W, 3)
         self.batch = int(batch)
-        self.pool = ThreadPoolExecutor(self.threads, thread_name_prefix="ofx-decode") if self.threads else None
+        self._own_pool = pool is None
+        self.pool = (pool if pool is not None else ThreadPoolExecutor(self.threads, thread_name_prefix="ofx-decode")) if self.threads else None
         # two rings of pinned staging buffers: full batches, and single frames (a key-frame request must not pin a whole batch:
         # 75 MB at 64 x 512x768)
         self._free: Dict[int, Deque[torch.Tensor]] = {1: deque(), self.batch: deque()}
@@ -123,9 +132,9 @@ class FrameLoader:
         return out
 
     def close(self) -> None:
-        if self.pool:
+        if self.pool and self._own_pool:
             self.pool.shutdown(wait=True, cancel_futures=True)
-            self.pool = None
+        self.pool = None
 
     def __enter__(self):
         return self
@@ -138,11 +147,12 @@ class FrameWriter:
     """Asynchronous `video.put_ai_frame(i, frame)` for device-resident frames.  `put` returns as soon as the D2H copy is enqueued
     (it blocks only when all `slots` staging buffers are still waiting for their encoder); `flush()` waits for every file."""
 
-    def __init__(self, video, device, threads: int = 4, slots: int = 32):
+    def __init__(self, video, device, threads: int = 4, slots: int = 32, pool: Optional[ThreadPoolExecutor] = None):
         self.video, self.device = video, torch.device(device)
         self.threads = max(0, int(threads))
         self.cuda = self.device.type == "cuda"
-        self.pool = ThreadPoolExecutor(self.threads, thread_name_prefix="ofx-encode") if self.threads else None
+        self._own_pool = pool is None
+        self.pool = (pool if pool is not None else ThreadPoolExecutor(self.threads, thread_name_prefix="ofx-encode")) if self.threads else None
         self._stream = torch.cuda.Stream(device=self.device) if self.cuda and self.threads else None
         self._sem = threading.Semaphore(max(2, int(slots)))
         self._free: Dict[Tuple[int, ...], Deque[torch.Tensor]] = {}      # pinned staging buffers, by frame shape
@@ -218,6 +228,6 @@ class FrameWriter:
         try:
             self.flush()
         finally:
-            if self.pool:
+            if self.pool and self._own_pool:
                 self.pool.shutdown(wait=True)
-                self.pool = None
+            self.pool = None

@@ -96,13 +96,14 @@ class ClipPipeline:
 
     def __init__(self, algo, vae=None, render: Optional[Callable] = None, render_key: Optional[Callable] = None, batch: int = 64,
                  warp_mode: str = "bilinear", thres: float = 0.95, ksize: int = 7, mask_blur: float = 4.0, device=None,
-                 io_threads: Optional[int] = None, prefetch: int = 2, edge_batch: int = 16, group=None):
+                 io_threads: Optional[int] = None, prefetch: int = 2, edge_batch: int = 16, group=None, share_pool: bool = True):
         self.algo, self.vae = algo, vae
         self.render = render or _paste_raw
         self.render_key = render_key or (lambda raw: raw)
         self.batch, self.warp_mode, self.thres, self.ksize, self.mask_blur = int(batch), warp_mode, float(thres), int(ksize), float(mask_blur)
         self.device = torch.device(device if device is not None else algo.device)
         self.group = group
+        self.share_pool = bool(share_pool)
         # host side (hostio.py): PNG decode / encode on `io_threads` workers each, `prefetch` batches decoded ahead of the GPU;
         # io_threads = 0 runs all of it inline on the calling thread (the reference's behaviour)
         self.io_threads = default_io_threads() if io_threads is None else max(0, int(io_threads))
@@ -171,7 +172,8 @@ class ClipPipeline:
             for b0 in range(0, len(mine), self.batch):
                 units.append((seg, mine[b0:b0 + self.batch]))
         units = split_edge_batches(units, self.edge_batch)
-        loader = hostio.FrameLoader(video, self.device, threads=self.io_threads, slots=self.prefetch + 1, batch=self.batch)
+        loader = hostio.FrameLoader(video, self.device, threads=self.io_threads, slots=self.prefetch + 1, batch=self.batch,
+                                    pool=getattr(writer, "pool", None) if self.share_pool else None)
         tickets = {}
 
         def ahead(k: int) -> None:
@@ -247,7 +249,11 @@ class ClipPipeline:
             self._check_collective()
         flags = flags if flags is not None else self.shared_flags(video)
         # staging slots for three batches: `put` must never wait for an encoder while the next batch's kernels are still to be enqueued
-        writer = hostio.FrameWriter(video, self.device, threads=self.io_threads, slots=3 * self.batch)
+        # one pool of 2 x io_threads workers for decode AND encode (round 6): a rank's decoders are idle while its last frames are being
+        # encoded and its encoders while the first are being decoded -- with a single 64-frame batch per rank (BASELINE configs[3])
+        # those two ends are a seventh of the run
+        pool = hostio.shared_pool(self.io_threads) if self.share_pool else None
+        writer = hostio.FrameWriter(video, self.device, threads=self.io_threads, slots=3 * self.batch, pool=pool)
         keys = []
         try:
             for pkt, raw, idx in self.packets(video, flags, writer=writer):
@@ -260,6 +266,12 @@ class ClipPipeline:
                 writer.close()                               # stop the encoders; what they have to say must not replace the failure above
             except Exception:
                 pass
+            if pool is not None:
+                pool.shutdown(wait=True, cancel_futures=True)
             raise
-        writer.close()                                       # flush: joins the encoders, re-raises their first failure
+        try:
+            writer.close()                                   # flush: joins the encoders, re-raises their first failure
+        finally:
+            if pool is not None:
+                pool.shutdown(wait=True)
         return keys

@@ -32,7 +32,7 @@ if ROOT not in sys.path:
 
 
 def measure(n_frames: int = 256, io_threads=None, seg: int = 64, batch: int = 64, keep: bool = False, reps: int = 2, inline: bool = True,
-            edge_batch: int = 16) -> dict:
+            edge_batch: int = 16, share_pool: bool = True) -> dict:
     import bench
     from sd_animation_optical_flow_amd import pdcnet_of, pipeline
     from sd_animation_optical_flow_amd.workspace import VideoData
@@ -59,7 +59,7 @@ def measure(n_frames: int = 256, io_threads=None, seg: int = 64, batch: int = 64
 
         def run(threads):
             pipe = pipeline.ClipPipeline(algo, batch=batch, warp_mode="bilinear", thres=0.95, ksize=7, io_threads=threads,
-                                         edge_batch=edge_batch)
+                                         edge_batch=edge_batch, share_pool=share_pool)
             shutil.rmtree(os.path.join(root, "ai-frames"))
             os.makedirs(os.path.join(root, "ai-frames"))
             torch.cuda.synchronize()
@@ -97,7 +97,7 @@ def measure(n_frames: int = 256, io_threads=None, seg: int = 64, batch: int = 64
         e, cpu_s = max(run(io_threads) for _ in range(max(1, reps)))
         out = {"workload": f"{n}-frame 512x768 workspace, {n_seg} key-frame segments, ClipPipeline.run (flow both ways + forward-backward "
                            f"confidence, warp + mask, SD-inpaint inputs, render, PNG in / PNG out), 1 GPU",
-               "frames": n, "png_mb_per_frame": round(png_mb, 3), "io_threads": io_threads, "edge_batch": edge_batch,
+               "frames": n, "png_mb_per_frame": round(png_mb, 3), "io_threads": io_threads, "edge_batch": edge_batch, "share_pool": share_pool,
                "cores": bench.usable_cores(),
                "end_to_end_fps": round(e, 2), "device_only_fps": round(d, 2), "ratio": round(e / d, 4),
                "host_cpu_s_per_frame": round(cpu_s, 5), "cores_for_8_ranks": round(8 * e * cpu_s, 1), "extract_s": round(t_extract, 2)}
@@ -115,4 +115,5 @@ if __name__ == "__main__":
     nf = int(sys.argv[1]) if len(sys.argv) > 1 else 256
     th = int(sys.argv[2]) if len(sys.argv) > 2 else None
     eb = int(sys.argv[3]) if len(sys.argv) > 3 else 16
-    print(json.dumps(measure(nf, th, edge_batch=eb)))
+    sp = (sys.argv[4] != "0") if len(sys.argv) > 4 else True
+    print(json.dumps(measure(nf, th, edge_batch=eb, share_pool=sp)))
