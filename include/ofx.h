@@ -269,11 +269,16 @@ int ofx_preprocess_u8(const uint8_t* img, float* out, long npix, int bgr, void* 
 int ofx_corr_slice_floats(int h_l, int w_l);      /* ceil(h_l/4) * ceil(w_l/8) * 32 */
 int ofx_corr_volume(const float* f1, const float* f2, float* const* pyr, int B, int h, int w, int D,
                     int levels, void* stream);
-/* The same pyramid with the volume GEMM in split-bf16 arithmetic (opt-in; RAFT/core/corr.py:52-60 computes it in fp32):
- * planes = 2 -> "bf16x3" (each fp32 operand = hi + lo bf16; products hh + hl + lh, ~16 mantissa bits),
- * planes = 3 -> "bf16x6" (hi + mid + lo; the six products >= 2^-16: fp32-level accuracy) on v_mfma_f32_32x32x16_bf16 with fp32
- * accumulation.  shared_f2 != 0: f2 is ONE feature map [h*w, D] shared by the B pairs (a key frame).  Needs D == 256, h % 8 == 0,
- * w % 16 == 0, levels >= 2 and (h*w)^2 * 4 < 2 GiB per pair; anything else returns OFX_EINVAL (use ofx_corr_volume). */
+/* The same pyramid on the "A-stationary" volume kernel (csrc/corr_split.hip: all of K = 256 for a wave's rows in registers, the other
+ * operand streamed through LDS, whole-line stores):
+ *   planes = 1 -> exact fp32 on v_mfma_f32_32x32x2_f32: BIT-IDENTICAL to ofx_corr_volume on every level (what ofx_raft_forward runs
+ *                 wherever the batch fills the part);
+ *   planes = 2 -> "bf16x3" (opt-in; RAFT/core/corr.py:52-60 computes in fp32): each fp32 operand = hi + lo bf16, products hh + hl + lh,
+ *                 ~16 mantissa bits;
+ *   planes = 3 -> "bf16x6" (opt-in): hi + mid + lo, the six products >= 2^-16: fp32-level accuracy;
+ * both split forms on v_mfma_f32_32x32x16_bf16 with fp32 accumulation.  shared_f2 != 0: f2 is ONE feature map [h*w, D] shared by the
+ * B pairs (a key frame).  Needs D == 256, h % 8 == 0, w % 16 == 0, levels >= 2 and (h*w)^2 * 4 < 2 GiB per pair; anything else returns
+ * OFX_EINVAL (use ofx_corr_volume). */
 int ofx_corr_volume_split(const float* f1, const float* f2, float* const* pyr, int B, int h, int w, int D,
                           int levels, int planes, int shared_f2, void* stream);
 /* CorrBlock.__call__ on the blocked pyramid: out[m, l*(2r+1)^2 + i*(2r+1) + j] for coords [B*h*w][2];

@@ -470,10 +470,14 @@ int launch_vol(VolArgs a, int planes, hipStream_t s) {
     a.swz = (a.ntask % 8 == 0) ? 1 : 0;
     const size_t ldsb = 2 * kKS * np * 1024 + 4 * rb * 8192;
     auto go = [&](auto kern) {
-        static size_t allowed = 0;      // per instantiation (a generic lambda's body is one per kernel type): > 64 KB of dynamic LDS
-        if (allowed < ldsb) {
+        // > 64 KB of dynamic LDS: allowed once per instantiation (a generic lambda's body is one per kernel type) and device
+        static size_t allowed[64] = {};
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        dev &= 63;
+        if (allowed[dev] < ldsb) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb);
-            allowed = ldsb;
+            allowed[dev] = ldsb;
         }
         hipLaunchKernelGGL(kern, dim3((unsigned)a.ntask), dim3(256), ldsb, s, a);
     };
