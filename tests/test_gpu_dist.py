@@ -47,6 +47,23 @@ def test_rccl_one_rank_bench_path(cuda):
     assert out["n_gpus"] == 1 and out["ranks_seen"] == 1 and out["value"] > 0
 
 
+def test_bench_workspace_mode_on_rccl_one_rank(cuda):
+    """`bench.py --workspace` with the collective path forced on (one rank, `nccl` = RCCL): the workspace path travels by
+    `broadcast_object_list`, the per-rank records by `all_gather_object`, the real `ClipPipeline.run` (HIP kernels, asynchronous host
+    side) writes every AI frame of a 12-frame segment."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "1", "--batch", "4", "--workspace",
+                        "--ws-segment", "12", "--no-volsplit", "--no-pipeline"] + _FAST,
+                       capture_output=True, text=True, timeout=900, cwd=ROOT,
+                       env=_env(OFX_BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), WORLD_SIZE="1", RANK="0",
+                                LOCAL_RANK="0"))
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.strip().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    ws = json.loads(lines[0])["workspace_ranks"]
+    assert ws["ranks"] == 1 and ws["frames"] == 12 and ws["every_frame_written"] and ws["compute"] == "hip"
+    assert ws["per_rank"][0]["frames"] == 12 and ws["per_rank"][0]["end_to_end_fps"] > 0
+
+
 _WORKER = r"""
 import os, sys, torch, torch.distributed as dist
 sys.path.insert(0, sys.argv[1])
