@@ -38,13 +38,14 @@ class PDCNetPlus:
     """Flow + confidence estimator with the duck type of the reference's `PDCNetPlus` (pdcnet_of.py:45-75)."""
 
     def __init__(self, ckpt_path="pre_trained_models/PDCNet_plus_m.pth.tar", device=None, iters: int = 20,
-                 confidence_sigma: float = 3.0, precision: str = "fp32"):
+                 confidence_sigma: float = 3.0, precision: str = "fp32", volume_precision: Optional[str] = None):
         self.state_dict = load_checkpoint(ckpt_path)
         self.precision = precision
+        self.volume_precision = volume_precision       # extension: 'bf16x6' / 'bf16x3' = ONLY the correlation volume in split-bf16 form
         self.iters = int(iters)
         self.sigma = float(confidence_sigma)
         self.device = torch.device(device) if device is not None else torch.device("cuda")
-        self.network = RaftEngine(self.state_dict, self.device, precision=precision)   # like `.cuda()` at pdcnet_of.py:61
+        self.network = RaftEngine(self.state_dict, self.device, precision=precision, volume_precision=volume_precision)   # like `.cuda()` at pdcnet_of.py:61
 
     def to(self, device):
         """`pdcnet_model.to(device)` (ofgen_keyframe_inpaint.py:555).  Moving re-uploads the weights."""
@@ -55,7 +56,7 @@ class PDCNetPlus:
         new = device.index if device.index is not None else torch.cuda.current_device()
         if cur != new:
             self.device = device
-            self.network = RaftEngine(self.state_dict, device, precision=self.precision)
+            self.network = RaftEngine(self.state_dict, device, precision=self.precision, volume_precision=self.volume_precision)
         return self
 
     # ---- device-resident core ------------------------------------------------------------------
@@ -179,9 +180,9 @@ def _unpad(t: torch.Tensor, H: int, W: int) -> torch.Tensor:
     return t[:, y0:y0 + H, x0:x0 + W].contiguous()
 
 
-def create_of_algo(ckpt, precision: str = "fp32") -> PDCNetPlus:
-    """pdcnet_of.py:77-79.  `precision` is an extension (default: the reference's fp32 arithmetic)."""
-    return PDCNetPlus(ckpt, precision=precision)
+def create_of_algo(ckpt, precision: str = "fp32", volume_precision: Optional[str] = None) -> PDCNetPlus:
+    """pdcnet_of.py:77-79.  `precision` / `volume_precision` are extensions (default: the reference's fp32 arithmetic everywhere)."""
+    return PDCNetPlus(ckpt, precision=precision, volume_precision=volume_precision)
 
 
 # --------------------------------------------------------------------------------------------------
