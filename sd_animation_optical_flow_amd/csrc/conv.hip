@@ -1163,24 +1163,24 @@ int launch_tile_uk(const ConvK& k, int epi, bool norm, int nz, hipStream_t s) {
         case OFX_EPI_PLAIN:
             if (k.act >= OFX_ACT_SIGMOID) {
                 if (norm) return OFX_EINVAL;   // fused-norm producer layers are followed by ReLU / identity only
-                hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, kEpiPlainT, false, BK, PREC, KS, SK, UK>), grid, block, 0, s, k);
+                OFX_LAUNCH((igemm_kernel<BM, BN, WM, WN, kEpiPlainT, false, BK, PREC, KS, SK, UK>), grid, block, s, k);
             } else if (norm) {
-                hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, OFX_EPI_PLAIN, true, BK, PREC, KS, SK, UK>), grid, block, 0, s, k);
+                OFX_LAUNCH((igemm_kernel<BM, BN, WM, WN, OFX_EPI_PLAIN, true, BK, PREC, KS, SK, UK>), grid, block, s, k);
             } else {
-                hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, OFX_EPI_PLAIN, false, BK, PREC, KS, SK, UK>), grid, block, 0, s, k);
+                OFX_LAUNCH((igemm_kernel<BM, BN, WM, WN, OFX_EPI_PLAIN, false, BK, PREC, KS, SK, UK>), grid, block, s, k);
             }
             break;
-        case OFX_EPI_GRU_ZR: hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, OFX_EPI_GRU_ZR, false, BK, PREC, KS, SK, UK>), grid, block, 0, s, k); break;
-        case OFX_EPI_GRU_Q: hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, OFX_EPI_GRU_Q, false, BK, PREC, KS, SK, UK>), grid, block, 0, s, k); break;
+        case OFX_EPI_GRU_ZR: OFX_LAUNCH((igemm_kernel<BM, BN, WM, WN, OFX_EPI_GRU_ZR, false, BK, PREC, KS, SK, UK>), grid, block, s, k); break;
+        case OFX_EPI_GRU_Q: OFX_LAUNCH((igemm_kernel<BM, BN, WM, WN, OFX_EPI_GRU_Q, false, BK, PREC, KS, SK, UK>), grid, block, s, k); break;
         case OFX_EPI_FLOW:
             if constexpr (UK != 2) {
-                hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, OFX_EPI_FLOW, false, BK, PREC, KS, SK, UK>), grid, block, 0, s, k);
+                OFX_LAUNCH((igemm_kernel<BM, BN, WM, WN, OFX_EPI_FLOW, false, BK, PREC, KS, SK, UK>), grid, block, s, k);
                 break;
             }
             return OFX_EINVAL;
         case kEpiVolPool:
             if constexpr (BM == 128 && BN == 128 && BK == 16 && KS == 1 && !SK && UK != 2) {
-                hipLaunchKernelGGL((igemm_kernel<128, 128, 64, 64, kEpiVolPool, false, 16, PREC, 1, false, UK>), grid, block, 0, s, k);
+                OFX_LAUNCH((igemm_kernel<128, 128, 64, 64, kEpiVolPool, false, 16, PREC, 1, false, UK>), grid, block, s, k);
                 break;
             }
             return OFX_EINVAL;

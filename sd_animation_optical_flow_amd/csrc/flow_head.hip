@@ -175,10 +175,10 @@ int ofx_flow_head_launch(const float* x, int ldx, const float* w, int Kpad, cons
     if (strips <= 1024) {
         // a single pair has 192 strips: as four-wave workgroups they would sit on 48 of the 256 CUs, each wave waiting on its own 60
         // dependent-latency loads; one wave per workgroup spreads them over the chip (12.6 -> 11.1 us per launch on one 512x768 pair)
-        hipLaunchKernelGGL(flow_head_kernel, dim3((unsigned)strips), dim3(64), 0, s, a);
+        OFX_LAUNCH(flow_head_kernel, dim3((unsigned)strips), dim3(64), s, a);
         return ofx_launch_status();
     }
     const int blocks = (int)std::min<long>((strips + 3) / 4, 256L * 16);   // one strip per wavefront, grid-stride beyond 16 workgroups per CU
-    hipLaunchKernelGGL(flow_head_kernel, dim3(blocks), dim3(256), 0, s, a);
+    OFX_LAUNCH(flow_head_kernel, dim3(blocks), dim3(256), s, a);
     return ofx_launch_status();
 }

@@ -32,6 +32,25 @@ struct OfxProfScope {
     void flops(double f);   // executed FLOPs of the bracketed launch (reported by ofx_prof_collect)
 };
 
+// One-shot completion event for the NEXT convolution / flow-head launch of this thread: the launcher hands it to
+// hipExtLaunchKernelGGL as the kernel's own stop event, so the dependency edge to another stream rides on the dispatch packet's
+// completion signal instead of a marker packet behind it (hipEventRecord): the caller's stream does not stall on the marker.
+// The launcher that consumes it clears it; a caller that finds it still set after the call records the event the plain way.
+extern thread_local hipEvent_t ofx_tl_stop_event;
+#ifdef __HIPCC__
+#include <hip/hip_ext.h>
+#define OFX_LAUNCH(kern, grid, block, s, ...)                                                      \
+    do {                                                                                           \
+        hipEvent_t ofx_ev_ = ofx_tl_stop_event;                                                    \
+        if (ofx_ev_) {                                                                             \
+            ofx_tl_stop_event = nullptr;                                                           \
+            hipExtLaunchKernelGGL(kern, grid, block, 0, s, nullptr, ofx_ev_, 0, __VA_ARGS__);      \
+        } else {                                                                                   \
+            hipLaunchKernelGGL(kern, grid, block, 0, s, __VA_ARGS__);                              \
+        }                                                                                          \
+    } while (0)
+#endif
+
 static inline int ofx_launch_status() {
     hipError_t e = hipGetLastError();
     return (int)e;

@@ -12,6 +12,8 @@
 #include <cstdio>
 #include <cstring>
 
+thread_local hipEvent_t ofx_tl_stop_event = nullptr;
+
 namespace {
 struct Rec {
     int name_id;

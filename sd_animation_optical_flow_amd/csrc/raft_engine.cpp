@@ -376,6 +376,19 @@ struct Streams {
         OFX_HIP_CHECK(hipStreamWaitEvent(main, r->ev_join[i], 0));
         return 0;
     }
+    // The same two edges with the event riding on a kernel's own dispatch packet (ofx_tl_stop_event, ofx_internal.h) instead of a
+    // marker packet behind it: arm_*() before the launch that ends the producing chain, *_armed() where fork() / join() would stand.
+    // On a single 512x768 pair the marker of fork() held the caller's stream for ~7 us per iteration (profiles/r05_single_pair_gap_pairs.txt).
+    static bool stop_events() { static const bool off = getenv("OFX_NO_STOP_EVENT") != nullptr; return !off; }
+    bool arm_fork() const { if (!on || !stop_events()) return false; ofx_tl_stop_event = r->ev_fork; return true; }
+    bool arm_join(int i) const { if (!on || !stop_events()) return false; ofx_tl_stop_event = r->ev_join[i]; return true; }
+    static bool taken() {   // did the launcher hand the armed event to its kernel?  (if not: disarm, the caller takes the plain edge)
+        const bool t = ofx_tl_stop_event == nullptr;
+        ofx_tl_stop_event = nullptr;
+        return t;
+    }
+    int fork_armed(int i) const { OFX_HIP_CHECK(hipStreamWaitEvent(r->aux[i], r->ev_fork, 0)); return 0; }
+    int join_armed(int i) const { OFX_HIP_CHECK(hipStreamWaitEvent(main, r->ev_join[i], 0)); return 0; }
 };
 
 constexpr size_t SK_BYTES = 65536 + (size_t)1024 * 4 * 64 * 64 * sizeof(float);   // counters + 1024 tiles x 4 splits (conv.hip)
@@ -612,11 +625,14 @@ static int run_recurrence(ofx_raft* r, const RaftWs& ws, int B, int h, int w, in
     auto C = [&](const char* k) -> const ConvW& { return r->convs[k]; };
     const float* pyr_c[LEVELS] = {ws.pyr[0], ws.pyr[1], ws.pyr[2], ws.pyr[3]};
     const int rd2 = (2 * RADIUS + 1) * (2 * RADIUS + 1);
+    bool fork_on_kernel = false;   // the previous iteration's flow head carries ev_fork
     for (int it = 0; it < iters && !L.st; ++it) {
         // flow features (update.py:93-94) on the side stream, from the flow the previous iteration left
-        if ((L.st = S.fork(0))) break;
+        if ((L.st = fork_on_kernel ? S.fork_armed(0) : S.fork(0))) break;
         LF.conv(C("convf1"), ws.frows, FROW, FROW, nullptr, 0, 0, ws.f1, 128, B, h, w, 1, OFX_ACT_RELU);   // 7x1 over the flow rows
+        const bool join_armed = S.arm_join(0);
         LF.conv(C("convf2"), ws.f1, 128, 128, nullptr, 0, 0, ws.corflo + 192, 256, B, h, w, 1, OFX_ACT_RELU);
+        const bool join_on_kernel = join_armed && Streams::taken();
         if ((L.st = LF.st)) break;
         // correlation features at the current estimate
         if (!alt) {
@@ -632,7 +648,7 @@ static int run_recurrence(ofx_raft* r, const RaftWs& ws, int B, int h, int w, in
         // motion encoder (update.py:88-97)
         L.conv(C("convc1"), ws.corr, CORR_LD, CORR_LD, nullptr, 0, 0, ws.c1, 256, B, h, w, 1, OFX_ACT_RELU);
         L.conv(C("convc2"), ws.c1, 256, 256, nullptr, 0, 0, ws.corflo, 256, B, h, w, 1, OFX_ACT_RELU);
-        if (!L.st) L.st = S.join(0);
+        if (!L.st) L.st = join_on_kernel ? S.join_armed(0) : S.join(0);
         L.conv(C("conv"), ws.corflo, 256, 256, nullptr, 0, 0, ws.hx + MOT_OFF, HX_LD, B, h, w, 1, OFX_ACT_RELU);
         // SepConvGRU (update.py:44-60): horizontal then vertical pass
         for (int pass = 1; pass <= 2; ++pass) {
@@ -650,8 +666,10 @@ static int run_recurrence(ofx_raft* r, const RaftWs& ws, int B, int h, int w, in
         L.conv(C("fh1"), ws.hx, HX_LD, HD, nullptr, 0, 0, ws.c1, 256, B, h, w, 1, OFX_ACT_RELU);
         if (!L.st) {   // 256 -> 2 channels: dedicated reduction kernel instead of a 1/16-utilised GEMM tile
             const ConvW& f2 = C("fh2");
+            const bool fork_armed = it + 1 < iters && S.arm_fork();
             L.st = ofx_flow_head_launch(ws.c1, 256, f2.w, (int)f2.kpad, f2.shift, ws.coords1, ws.hx + FLOW_OFF, HX_LD, ws.frows, B, h,
                                         w, s);
+            fork_on_kernel = fork_armed && Streams::taken();
         }
     }
     // mask head (update.py:122-125,135) on the final hidden state, then convex upsample
