@@ -135,10 +135,20 @@ __global__ __launch_bounds__(256 * KS, (BK == 16 && KS == 1) ? ((PREC == 3 || PR
     constexpr int ROWB = BK * 2 + 16;                       // bytes per staged bf16 row
     constexpr int NPC = X6 ? 3 : 2;                         // bf16 pieces per operand element
     constexpr int STAGE = PREC ? ((BM + BN_ST) * ROWB * NPC) / 4 : (BM + BN_ST) * LDK;   // floats per stage
+    // BSWZ (the fp32 64-row patch tile, i.e. the small-grid schedule): the two weight stages are UNPADDED 128-byte rows whose eight
+    // 16-byte slots are XOR-swizzled with (row >> 1) & 7 -- 16 consecutive rows of one slot then cover the 64 banks exactly (row parity
+    // picks the half, the swizzle the quad), which is what the LDK padding buys elsewhere.  It takes 2 KB off the workgroup (34 564 ->
+    // 32 516 bytes): FIVE workgroups share a CU's 160 KB instead of four, so that the 1152-workgroup layers of a single pair
+    // (`convc2`: 288 tiles x 4 splits) run in one round instead of 1024 + a tail of 128 at one workgroup per CU.
+#ifdef OFX_NO_BSWZ   // A/B build (tools/build_variant.sh nobswz -DOFX_NO_BSWZ): the padded weight stages, four workgroups per CU
+    constexpr bool BSWZ = false;
+#else
+    constexpr bool BSWZ = PATCH && PREC == 0 && BM == 64 && BK == 32;
+#endif
     static_assert((BM / WM) * (BN / WN) == 4, "4 waves per workgroup");
     static_assert(KS == 1 || KS == 2, "one or two pipelines");
     static_assert(KS == 1 || 2 * STAGE * KS >= 256 * TM * TN * 16, "accumulator exchange must fit the staging buffers");
-    __shared__ __attribute__((aligned(16))) float smem_all[!PATCH ? 2 * STAGE * KS : PREC == 0 ? (kPatchRows + 2 * BN_ST) * LDK : (kPatchRows + 2 * BN_ST) * (X6 ? 3 : 2) * (ROWB / 4)];
+    __shared__ __attribute__((aligned(16))) float smem_all[!PATCH ? 2 * STAGE * KS : BSWZ ? kPatchRows * LDK + 2 * BN_ST * BK : PREC == 0 ? (kPatchRows + 2 * BN_ST) * LDK : (kPatchRows + 2 * BN_ST) * (X6 ? 3 : 2) * (ROWB / 4)];
     const int grp = KS == 1 ? 0 : (int)(threadIdx.x >> 8);      // pipeline this thread belongs to
     float* const smem = smem_all + grp * (2 * STAGE);
 
@@ -225,9 +235,10 @@ __global__ __launch_bounds__(256 * KS, (BK == 16 && KS == 1) ? ((PREC == 3 || PR
         a_ix0[i] = ox * p.stride - p.padW;
         apix[i] = b * p.Hin * p.Win + a_iy0[i] * p.Win + a_ix0[i];   // may be negative (padding)
     }
+    const int brow0 = BSWZ ? j0 : r0;   // BSWZ: a 16-lane write pass covers two whole consecutive rows (opposite parities)
     int browb[B_PER];
 #pragma unroll
-    for (int i = 0; i < B_PER; ++i) browb[i] = (n0 + r0 + RPG * i) * (p.Kpad * 4) + kq * 16;   // rows past Cout fall off the extent
+    for (int i = 0; i < B_PER; ++i) browb[i] = (n0 + brow0 + RPG * i) * (p.Kpad * 4) + kq * 16;   // rows past Cout fall off the extent
     // UK: byte offset of (row pixel, this thread's float4 slot) in each input segment
     int rowb0[UK ? A_PER : 1], rowb1[UK ? A_PER : 1];
     if constexpr (UK) {
@@ -276,7 +287,7 @@ __global__ __launch_bounds__(256 * KS, (BK == 16 && KS == 1) ? ((PREC == 3 || PR
         // ROWB bytes each -- patch hi | patch lo | two stages of (weights hi | weights lo)
         constexpr int AROWF = PREC == 0 ? LDK : ROWB / 4;    // floats per staged row (of one piece)
         constexpr int APIECE = kPatchRows * AROWF;           // floats per A piece
-        constexpr int BPIECE = BN_ST * AROWF;
+        constexpr int BPIECE = BN_ST * (BSWZ ? BK : AROWF);
         float* const Apatch = smem_all;
         constexpr int NPIECE = PREC == 0 ? 1 : X6 ? 3 : 2;
         float* const Bst = smem_all + NPIECE * APIECE;
@@ -321,6 +332,16 @@ __global__ __launch_bounds__(256 * KS, (BK == 16 && KS == 1) ? ((PREC == 3 || PR
         }
 #pragma unroll
         for (int j = 0; j < TN; ++j) bfr[j] = PREC == 0 ? (wn * WN + j * 32 + frow) * LDK + fk : (wn * WN + j * 32 + frow) * ROWB + (lane >> 5) * 16;
+        // BSWZ: float offset of the fragment read of k-step ks = row * 32 + 4 * ((2 ks + half) ^ ((row >> 1) & 7))
+        int bfz[BSWZ ? TN : 1][BSWZ ? BK / 8 : 1];
+        if constexpr (BSWZ) {
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int n = wn * WN + j * 32 + frow;
+#pragma unroll
+                for (int ks = 0; ks < BK / 8; ++ks) bfz[j][ks] = n * BK + 4 * ((2 * ks + (lane >> 5)) ^ ((n >> 1) & 7));
+            }
+        }
 
         // fp32 -> (hi, lo) bf16 pair, round-to-nearest-even both times (as in the general path's commit)
         auto split_store = [&](char* hi_row, char* lo_row, float4 v) __attribute__((always_inline)) {
@@ -407,7 +428,10 @@ __global__ __launch_bounds__(256 * KS, (BK == 16 && KS == 1) ? ((PREC == 3 || PR
         auto b_commit = [&](float* Bs) __attribute__((always_inline)) {
             if constexpr (PREC == 0) {
 #define OFX_B_COMMIT(i) \
-    if constexpr (B_PER > i) *reinterpret_cast<float4*>(&Bs[(r0 + RPG * i) * LDK + kq * 4]) = rb##i;
+    if constexpr (B_PER > i) { \
+        if constexpr (BSWZ) *reinterpret_cast<float4*>(&Bs[(brow0 + RPG * i) * BK + 4 * (kq ^ (((brow0 + RPG * i) >> 1) & 7))]) = rb##i; \
+        else *reinterpret_cast<float4*>(&Bs[(r0 + RPG * i) * LDK + kq * 4]) = rb##i; \
+    }
                 OFX_B_COMMIT(0) OFX_B_COMMIT(1) OFX_B_COMMIT(2) OFX_B_COMMIT(3)
 #undef OFX_B_COMMIT
             } else {
@@ -500,7 +524,7 @@ __global__ __launch_bounds__(256 * KS, (BK == 16 && KS == 1) ? ((PREC == 3 || PR
 #pragma unroll
                 for (int i = 0; i < TM; ++i) fa[i] = *reinterpret_cast<const float4*>(&As[afr[i] + ks * 8]);
 #pragma unroll
-                for (int j = 0; j < TN; ++j) fb[j] = *reinterpret_cast<const float4*>(&Bs[bfr[j] + ks * 8]);
+                for (int j = 0; j < TN; ++j) fb[j] = *reinterpret_cast<const float4*>(&Bs[BSWZ ? bfz[BSWZ ? j : 0][BSWZ ? ks : 0] : bfr[j] + ks * 8]);
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
