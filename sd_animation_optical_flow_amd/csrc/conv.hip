@@ -1436,7 +1436,11 @@ extern "C" int ofx_conv2d_alpha(const ofx_conv_desc* d, float alpha, void* strea
         // work per CU in tile units if the tiles are cut S ways: ceil(tiles * S / 256) / S -- take the S that
         // minimises it (ties: fewer splits), with at least six 32-wide chunks per split
         int S = 1;
-        if (tiles <= 1024 && nk32 >= 12) {
+        // (tiles up to 2048: with five workgroups per CU resident, `convc2` of four frames -- 1152 tiles = 4.5 per CU -- runs as
+        // 2304 half-K workgroups: 24.15 -> 23.98 ms per four frames; the scratch bound below still applies.  OFX_SK_MAX_TILES overrides)
+        static const char* skt_env = getenv("OFX_SK_MAX_TILES");
+        const long sk_max_tiles = skt_env ? atol(skt_env) : 2048;
+        if (tiles <= sk_max_tiles && nk32 >= 12) {
             double best = (double)((tiles + 255) / 256);
             for (int c = 2; c <= 4; ++c) {
                 if (nk32 / c < 6) break;
