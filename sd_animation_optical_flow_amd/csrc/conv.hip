@@ -1441,11 +1441,15 @@ extern "C" int ofx_conv2d_alpha(const ofx_conv_desc* d, float alpha, void* strea
         static const char* skt_env = getenv("OFX_SK_MAX_TILES");
         const long sk_max_tiles = skt_env ? atol(skt_env) : 2048;
         if (tiles <= sk_max_tiles && nk32 >= 12) {
-            double best = (double)((tiles + 255) / 256);
+            const double base = (double)((tiles + 255) / 256);
+            double best = base;
             for (int c = 2; c <= 4; ++c) {
                 if (nk32 / c < 6) break;
                 const double span = (double)((tiles * c + 255) / 256) / c;
-                if (span < best - 1e-9) { best = span; S = c; }
+                // a split must buy more balance than its seam costs: 4 % of the unsplit span per split (round 6: 960 tiles cut four
+                // ways for a nominal 4 -> 3.75 ran 7 % SLOWER than unsplit -- `conv` / GRU q of five frames; 1152 tiles cut in two
+                // for 5 -> 4.5 gained 3 %; the single pair's layers gain 25-37 %)
+                if (span < best - 1e-9 && span < base * (1.0 - 0.04 * c) + 1e-9) { best = span; S = c; }
             }
         }
         const size_t need = 65536 + (size_t)tiles * S * 64 * 64 * sizeof(float);

@@ -85,7 +85,13 @@ static inline int enc_chunk(int H, int W) {
 // executor therefore runs the independent chains of a forward side by side on separate HIP streams (the
 // three encoders; the flow branch of the motion encoder next to the correlation branch).  Large batches fill
 // the machine with every launch and stay on one stream.
-static inline bool overlap_pays(long M) { return M <= 32768; }
+static inline bool overlap_pays(long M) {
+    // (round 6 sweep at 512x768, M = 6144 per frame: four frames 23.9 ms with the side streams / 24.4 without, five 30.9 / 30.3, six
+    // 38.0 / 37.7; OFX_OVERLAP_MAX_M overrides)
+    static const char* e = getenv("OFX_OVERLAP_MAX_M");
+    static const long lim = e ? atol(e) : 28672;
+    return M <= lim;
+}
 
 struct Carver {
     char* base;
