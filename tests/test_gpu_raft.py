@@ -237,6 +237,41 @@ def test_small_grids_repeat_bit_for_bit(engine):
                 assert torch.equal(engine.forward(a, k, iters=it, serial=serial), ref), (B, H, W, serial)
 
 
+_EDGE_SCRIPT = r"""
+import hashlib, sys, torch
+sys.path.insert(0, sys.argv[1])
+from sd_animation_optical_flow_amd.raft import RaftEngine
+from sd_animation_optical_flow_amd.weights import random_state_dict
+eng = RaftEngine(random_state_dict(0), "cuda")
+g = torch.Generator(device="cuda").manual_seed(5)
+h = hashlib.sha256()
+for (B, H, W, it) in ((1, 384, 256, 7), (2, 336, 280, 5), (4, 256, 192, 4), (1, 768, 512, 3)):
+    a = torch.randint(0, 256, (B, H, W, 3), dtype=torch.uint8, device="cuda", generator=g)
+    k = torch.randint(0, 256, (H, W, 3), dtype=torch.uint8, device="cuda", generator=g)
+    h.update(eng.forward(a, k, iters=it).cpu().numpy().tobytes())
+print("FLOWS", h.hexdigest())
+"""
+
+
+def test_event_edges_on_kernels_match_marker_edges(cuda):
+    """Small grids run the flow branch of the motion encoder on a side stream; since round 6 its fork and join events ride on the
+    flow head's / convf2's own dispatch packets (hipExtLaunchKernelGGL stop events, OFX_LAUNCH) instead of hipEventRecord markers.
+    The switch is read once per process, so two child processes: the same flows, bit for bit, either way -- a dependency lost in
+    the plumbing would show as a different (or run-to-run unstable) result on these under-filled grids."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+    def run(extra):
+        env = dict(os.environ, **extra)
+        out = subprocess.run([sys.executable, "-c", _EDGE_SCRIPT, root], env=env, capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stderr[-2000:]
+        return [l for l in out.stdout.splitlines() if l.startswith("FLOWS")][-1]
+
+    on_kernels = run({})
+    assert on_kernels == run({}), "the kernel-carried edges do not repeat"
+    assert on_kernels == run({"OFX_NO_STOP_EVENT": "1"})
+
+
 # ------------------------------------------------------------------------------------------------
 # round 2: the benchmarked configuration itself, the reference's own vectors, and saturated gates
 # ------------------------------------------------------------------------------------------------
