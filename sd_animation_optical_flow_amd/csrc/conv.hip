@@ -1491,7 +1491,16 @@ extern "C" int ofx_conv2d_alpha(const ofx_conv_desc* d, float alpha, void* strea
     // the 128-row tiles also take maps that are not whole patches (the last patch of a row / column hangs over: its outside
     // pixels stage zeros and are masked in the epilogue); the small tile, whose grid feeds the split-K choice above, does not
     const bool whole = d->Hin % ph == 0 && d->Win % pw == 0;
-    k.patch = (!no_patch && d->precision == OFX_PREC_FP32 && shape_ok && d->stride == 1 && d->padH == d->KH / 2 && d->padW == d->KW / 2 &&
+    // ... as long as the overhang is cheap: the rows of a patch outside the map are multiplied like any others (a 68 x 120 map --
+    // 544x960 frames -- is 9 x 8 patches = 72 x 128 pixels: 1.13x the work).  Beyond a cover of OFX_PATCH_MAX_WASTE (default 1.09) a
+    // layer takes the scalar-coordinate / general kernels, which compute no row twice.  Measured, 16 frames, whole forward
+    // (tools/odd_sizes.py, patch kernel -> general kernels): cover 1.07 (720x1280) 218 -> 227 ms, 1.13 (544x960) 137 -> 117,
+    // 1.19 (600x800) 133 -> 117, 1.32 (776x520) 122 -> 107: the crossover sits near 1.09
+    static const char* waste_env = getenv("OFX_PATCH_MAX_WASTE");
+    static const double max_waste = waste_env ? atof(waste_env) : 1.09;
+    const double patch_waste = (double)(((d->Hin + ph - 1) / ph) * ph) * (double)(((d->Win + pw - 1) / pw) * pw) / ((double)d->Hin * d->Win);
+    const bool no_patch_here = no_patch || (!whole && d->tile == 0 && patch_waste > max_waste);   // (a forced tile keeps the patch kernel: the tests' way in)
+    k.patch = (!no_patch_here && d->precision == OFX_PREC_FP32 && shape_ok && d->stride == 1 && d->padH == d->KH / 2 && d->padW == d->KW / 2 &&
                d->Hin == d->Hout && d->Win == d->Wout && (whole || big) && k.cin % bk == 0 &&
                (d->c1 == 0 || d->c0 % bk == 0) && (!d->nmean || d->c1 == 0) && nz == 1 && (big || small) &&
                (bn == 64 || bn == 96 || bn == 128 || bn == 192) && d->epi != OFX_EPI_FLOW)
@@ -1537,7 +1546,8 @@ extern "C" int ofx_conv2d_alpha(const ofx_conv_desc* d, float alpha, void* strea
         // bf16x3 on the halo patch (128-row tiles, BK = 16): the fp32 -> (hi, lo) conversion of the A side then runs once per
         // 16-channel slab instead of once per tap
         const bool whole16 = d->Hin % 8 == 0 && d->Win % 16 == 0;
-        k.patch = (!no_patch && shape_ok && d->stride == 1 && d->padH == d->KH / 2 && d->padW == d->KW / 2 && d->Hin == d->Hout &&
+        const double waste16 = (double)(((d->Hin + 7) / 8) * 8) * (double)(((d->Win + 15) / 16) * 16) / ((double)d->Hin * d->Win);
+        k.patch = (!no_patch && (whole16 || d->tile != 0 || waste16 <= max_waste) && shape_ok && d->stride == 1 && d->padH == d->KH / 2 && d->padW == d->KW / 2 && d->Hin == d->Hout &&
                    d->Win == d->Wout && k.cin % 16 == 0 && (d->c1 == 0 || d->c0 % 16 == 0) && (!d->nmean || d->c1 == 0) && nz == 1 &&
                    bm == 128 && tile_bk != 32 && d->epi != OFX_EPI_FLOW)
                       ? 1 : 0;
