@@ -97,7 +97,7 @@ class PDCNetPlus:
         B, ns = tgt.shape[0], src.shape[0]
         if not shared and ns != B:
             raise RuntimeError("source / target batch sizes differ")
-        step = max(1, net.max_pairs(tgt.shape[1], tgt.shape[2]) // 2)
+        step = max(1, net.max_pairs_now(tgt.shape[1], tgt.shape[2], 2 * B) // 2)      # 32-bit offsets AND the memory free right now
         fts, fss, wps = [], [], []
         for b0 in range(0, B, step):
             t = tgt[b0:b0 + step]
@@ -132,7 +132,7 @@ class PDCNetPlus:
         H0, W0 = frames.shape[1], frames.shape[2]
         frames = self.network.pad_to_8(frames.contiguous())
         # one executor call addresses its operands with 32-bit offsets: 113 pairs at 512x768 but 21 at 1920x1080
-        max_flows = max(1, min(int(max_flows), self.network.max_pairs(frames.shape[1], frames.shape[2])))
+        max_flows = self.network.max_pairs_now(frames.shape[1], frames.shape[2], max_flows)   # ... and what fits the free memory
         need = {}                                    # directed flow (image1, image2) -> slot
         for s, t in pairs:
             need.setdefault((t, s), len(need))       # flow on t's grid into s

@@ -79,6 +79,7 @@ class RaftEngine:
         self._h = h
         self._ws: Optional[torch.Tensor] = None
         self._ws_key: Optional[Tuple[int, int, int]] = None
+        self.ws_budget_bytes: Optional[int] = None     # see pairs_that_fit
 
     def __del__(self):
         h = getattr(self, "_h", None)
@@ -97,6 +98,56 @@ class RaftEngine:
             self._ws = None
             self._ws = torch.empty((need,), dtype=torch.uint8, device=self.device)
         return self._ws
+
+    def pairs_that_fit(self, B: int, H: int, W: int) -> int:
+        """Largest batch <= B whose executor workspace (dominated by the all-pairs correlation pyramid: ~1.33 x (H/8 x W/8)^2 floats
+        per pair -- 201 MB at 512x768, 5.6 GB at 1080x1920, 89 GB at 2160x3840) fits the device memory that is free right now
+        (plus this engine's cached workspace and the caching allocator's idle blocks), so that a large batch of large frames is
+        processed in slices instead of failing in the allocator.  `ws_budget_bytes` (attribute) overrides the measured budget."""
+        L = _lib.lib()
+        budget = self.ws_budget_bytes
+        if budget is None and self._ws is not None and L.ofx_raft_workspace_bytes(self._h, B, H, W) <= self._ws.numel():
+            return B                       # the cached workspace already holds this batch: nothing to measure
+        if budget is None:
+            free, _total = torch.cuda.mem_get_info(self.device)
+            idle = torch.cuda.memory_reserved(self.device) - torch.cuda.memory_allocated(self.device)
+            have = self._ws.numel() if self._ws is not None else 0
+            budget = int(0.92 * (free + idle + have))
+        if L.ofx_raft_workspace_bytes(self._h, B, H, W) <= budget:
+            return B
+        lo, hi = 1, B                      # need(b) grows with b: largest b that fits (at least 1: let the allocator speak for itself)
+        while lo < hi:
+            mid = (lo + hi + 1) // 2
+            if L.ofx_raft_workspace_bytes(self._h, mid, H, W) <= budget:
+                lo = mid
+            else:
+                hi = mid - 1
+        return lo
+
+    def max_pairs_now(self, H: int, W: int, limit: Optional[int] = None) -> int:
+        """`max_pairs` further bounded by the device memory that is free right now, for the indexed-pairs calls (`forward_pairs`:
+        every pair may bring two images of its own -- the bound assumes so): what `pdcnet_of` slices its batches by."""
+        L = _lib.lib()
+        B = self.max_pairs(H, W) if limit is None else max(1, min(int(limit), self.max_pairs(H, W)))
+        Hp, Wp = (H + 7) // 8 * 8, (W + 7) // 8 * 8
+        need = lambda b: L.ofx_raft_workspace_bytes_pairs(self._h, 2 * b, b, Hp, Wp)
+        budget = self.ws_budget_bytes
+        if budget is None and self._ws is not None and need(B) <= self._ws.numel():
+            return B
+        if budget is None:
+            free, _total = torch.cuda.mem_get_info(self.device)
+            idle = torch.cuda.memory_reserved(self.device) - torch.cuda.memory_allocated(self.device)
+            budget = int(0.92 * (free + idle + (self._ws.numel() if self._ws is not None else 0)))
+        lo, hi = 1, B
+        if need(B) <= budget:
+            return B
+        while lo < hi:
+            mid = (lo + hi + 1) // 2
+            if need(mid) <= budget:
+                lo = mid
+            else:
+                hi = mid - 1
+        return lo
 
     @staticmethod
     def max_pairs(H: int, W: int) -> int:
@@ -167,6 +218,8 @@ class RaftEngine:
         elif not want_flow:
             raise ValueError("want_flow=False only makes sense together with warp_frame")
         max_pairs = self.max_pairs(H, W)
+        if B > 1:
+            max_pairs = min(max_pairs, self.pairs_that_fit(min(B, max_pairs), H, W))
         if B > max_pairs:
             outs = []
             for b0 in range(0, B, max_pairs):

@@ -237,6 +237,30 @@ def test_small_grids_repeat_bit_for_bit(engine):
                 assert torch.equal(engine.forward(a, k, iters=it, serial=serial), ref), (B, H, W, serial)
 
 
+def test_a_batch_larger_than_the_memory_budget_runs_in_slices(cuda, raft_sd):
+    """The executor's workspace grows with (H/8 x W/8)^2 per pair (the correlation pyramid).  RaftEngine.pairs_that_fit slices a
+    batch that would not fit the free device memory; here the budget is forced down to three pairs' worth: same flows (pairs are
+    independent; small and large grids differ by rounding only), and the slices really were taken."""
+    from sd_animation_optical_flow_amd.raft import RaftEngine
+    import bench
+    B, H, W = 8, 256, 192
+    frames, key, _, _ = bench.make_clip(B, H, W, torch.device("cuda"))
+    whole = RaftEngine(raft_sd)
+    ref = whole.forward(frames, key, iters=6)
+    eng = RaftEngine(raft_sd)
+    from sd_animation_optical_flow_amd import _lib
+    need3 = _lib.lib().ofx_raft_workspace_bytes(eng._h, 3, H, W)
+    eng.ws_budget_bytes = int(need3)
+    assert eng.pairs_that_fit(B, H, W) == 3 and eng.pairs_that_fit(2, H, W) == 2
+    out = eng.forward(frames, key, iters=6)
+    assert eng._ws.numel() <= need3                                   # never allocated more than the budget
+    assert tuple(out.shape) == tuple(ref.shape) and (out - ref).abs().max().item() < 1e-3
+    eng.ws_budget_bytes = 1                                           # nothing fits: one pair at a time, the allocator decides
+    assert eng.pairs_that_fit(B, H, W) == 1
+    up, low, warped = eng.forward(frames, key, iters=6, want_low=True, warp_frame=key)
+    assert (up - ref).abs().max().item() < 1e-3 and tuple(low.shape) == (B, H // 8, W // 8, 2) and tuple(warped.shape) == (B, H, W, 3)
+
+
 _EDGE_SCRIPT = r"""
 import hashlib, sys, torch
 sys.path.insert(0, sys.argv[1])

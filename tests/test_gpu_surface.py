@@ -374,6 +374,41 @@ def test_calc_pairs_honours_the_per_call_pair_limit(algo, monkeypatch):
     assert (got_f - want_f).abs().max().item() < 1e-4 and (got_c - want_c).abs().max().item() < 1e-4
 
 
+def test_pair_batches_are_sliced_by_the_memory_that_is_free(algo, monkeypatch):
+    """The executor's workspace grows with (H/8 x W/8)^2 per pair; RaftEngine.max_pairs_now bounds a call by the device memory that
+    is free (round 6).  Force the budget down to two pairs' worth: calc_pairs and the batched frame path slice accordingly and
+    return what the unsliced calls return."""
+    from sd_animation_optical_flow_amd import _lib
+    from sd_animation_optical_flow_amd.raft import RaftEngine
+    f1, f2 = _pair(12)
+    f3, _ = _pair(13)
+    dev = torch.from_numpy(np.stack([f1, f2, f3])).cuda()
+    pairs = [(s, t) for s in range(3) for t in range(3) if s != t]
+    want_f, want_c = algo.calc_pairs(dev, pairs)
+    want = algo.calc_batch_device(dev[0], dev[1:], bgr=True)
+    net = algo.network
+    Hp, Wp = (dev.shape[1] + 7) // 8 * 8, (dev.shape[2] + 7) // 8 * 8
+    calls = []
+    real = RaftEngine.forward_pairs
+
+    def spy(self, images, idx1, idx2, **kw):
+        calls.append(len(idx1))
+        return real(self, images, idx1, idx2, **kw)
+    monkeypatch.setattr(RaftEngine, "forward_pairs", spy)
+    try:
+        net.ws_budget_bytes = int(_lib.lib().ofx_raft_workspace_bytes_pairs(net._h, 4, 2, Hp, Wp))
+        assert net.max_pairs_now(Hp, Wp) == 2 and net.max_pairs_now(Hp, Wp, 1) == 1
+        got_f, got_c = algo.calc_pairs(dev, pairs)
+        assert max(calls) <= 2 and sum(calls) == 6
+        del calls[:]
+        got = algo.calc_batch_device(dev[0], dev[1:], bgr=True)    # two frames, both directions: four pairs -> two calls
+        assert calls == [2, 2]
+    finally:
+        net.ws_budget_bytes = None
+    assert (got_f - want_f).abs().max().item() < 1e-4 and (got_c - want_c).abs().max().item() < 1e-4
+    assert (got[0] - want[0]).abs().max().item() < 1e-4 and (got[1] - want[1]).abs().max().item() < 1e-4
+
+
 def test_keyframe_conv_device_resident_over_a_workspace(algo, tmp_path):
     """KeyframeConv (ofgen_keyframe_inpaint.py:655-674) over a `workspace.VideoData`: windows from `conv_indices`, scores
     reduced on the device.  Held to the reference's host formulation -- build the [N,N,H,W,3] matrix with
